@@ -1,0 +1,107 @@
+"""ctypes view of oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; the product package
+never does (tests/test_boundary.py greps for that).  Build with `make -C oracle`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+_d = C.POINTER(C.c_double)
+_f = C.POINTER(C.c_float)
+_i = C.POINTER(C.c_int32)
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(f"{_LIB_PATH} missing: run `make -C oracle` (or __graft_entry__.build())")
+    lib = C.CDLL(_LIB_PATH)
+    sig = {
+        "orc_params_default": (None, [_d, C.c_int]),
+        "orc_dynamics": (None, [_d, _d, _d, _d]),
+        "orc_rk4_step": (C.c_int, [_d, _d, _d, C.c_double]),
+        "orc_backend_step": (C.c_int, [_d, _d, _d, C.c_double, C.c_double]),
+        "orc_num_substeps": (C.c_int, [C.c_double, C.c_double]),
+        "orc_derived": (None, [_d, _d]),
+        "orc_clip_controls": (None, [_d, _d]),
+        "orc_pid_compute": (C.c_float, [_f, _f, C.c_float, C.c_float, C.c_float]),
+        "orc_wrap_angle": (C.c_double, [C.c_double]),
+        "orc_rate_agent": (None, [_f, _f, _d, _d, C.c_double, _d, C.c_double, _d]),
+        "orc_attitude_agent": (None, [_f, _f, _d, _d, C.c_int, C.c_double, _d, C.c_double, _d]),
+        "orc_hsa_agent": (None, [_f, _f, _d, _d, _d, _d, C.c_double, _d]),
+        "orc_waypoint_agent": (None, [_f, _f, _d, _d, _d, _d, C.c_double, _d]),
+        "orc_mission_update": (C.c_int, [_d, _d, C.c_int, _i, _d]),
+        "orc_cascade_step": (C.c_int, [_d, _f, _f, _d, _d, C.c_int, _i, _d, C.c_double, _d, _i]),
+        "orc_tracking_reward": (C.c_double, [_d, _d, _d, C.c_double, C.c_double, C.c_double, C.c_double, _d]),
+        "orc_settle_bonus": (C.c_double, [_d, _d, _d, C.c_double]),
+        "orc_env_reset": (None, [_d, _d, _d, _i, _d, _f]),
+        "orc_env_step": (None, [_d, _d, _d, _d, _i, _f, _d, _f, _d, _i, _i]),
+        "orc_sixdof_step_batch": (None, [_d, _d, _d, C.c_int64, C.c_double, C.c_int, C.c_int]),
+        "orc_env_step_batch": (None, [_d, _d, _d, _d, _i, _f, _f, _d, _i, _i, C.c_int64, C.c_int]),
+        "orc_cascade_step_batch": (None, [_d, _f, _f, _d, _d, C.c_int, _i, _d, _d, C.c_int64, C.c_double,
+                                          C.c_int, C.c_int]),
+        "orc_max_threads": (C.c_int, []),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()
+
+
+def dp(a):
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    return a.ctypes.data_as(_d)
+
+
+def fp(a):
+    assert a.dtype == np.float32 and a.flags.c_contiguous
+    return a.ctypes.data_as(_f)
+
+
+def ip(a):
+    assert a.dtype == np.int32 and a.flags.c_contiguous
+    return a.ctypes.data_as(_i)
+
+
+def params_default(aircraft_type=0):
+    from hcrl_amd import layout as L
+    P = np.zeros(L.FD_NP, dtype=np.float64)
+    lib.orc_params_default(dp(P), aircraft_type)
+    return P
+
+
+def dynamics(P, x, u):
+    x, u = np.ascontiguousarray(x, np.float64), np.ascontiguousarray(u, np.float64)
+    xd = np.zeros(12)
+    lib.orc_dynamics(dp(P), dp(x), dp(u), dp(xd))
+    return xd
+
+
+def derived(x):
+    x = np.ascontiguousarray(x, np.float64)
+    d = np.zeros(4)
+    lib.orc_derived(dp(x), dp(d))
+    return d
+
+
+def clip_controls(u):
+    u = np.ascontiguousarray(u, np.float64)
+    o = np.zeros(4)
+    lib.orc_clip_controls(dp(u), dp(o))
+    return o
+
+
+def rk4_step(P, x, u, dt):
+    """In-place on x (float64[12]); u already clipped."""
+    return lib.orc_rk4_step(dp(P), dp(x), dp(u), dt)
+
+
+def backend_step(P, x, u, dt, dt_physics=0.001):
+    return lib.orc_backend_step(dp(P), dp(x), dp(u), dt, dt_physics)

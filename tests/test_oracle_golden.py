@@ -1,0 +1,318 @@
+"""The CPU oracle (oracle/flight_oracle.c) against fixtures produced by RUNNING the reference
+(tests/golden/make_golden.py).  CPU-only.  This is what pins the oracle; the GPU parity tests then compare
+the HIP path against this oracle and against the same fixtures.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err, STATE_ANGLE_COLS
+import hcrl_amd
+from hcrl_amd import layout as L
+from hcrl_amd import config as cfgmod
+from hcrl_amd import samplers
+from hcrl_amd.params import AircraftParams, aircraft_params_for
+from hcrl_amd.flight_types import ControllerConfig
+
+
+def test_param_block_matches_oracle_defaults(oracle):
+    assert np.array_equal(AircraftParams().to_block(), oracle.params_default(0))
+    assert np.array_equal(aircraft_params_for("cessna").to_block(), oracle.params_default(1))
+
+
+def test_dynamics_single_eval(oracle):
+    g = load_golden("dynamics_eval.npz")
+    P = AircraftParams().to_block()
+    for x, u, xd in zip(g["x"], g["ctrl"], g["xdot"]):
+        got = oracle.dynamics(P, x, u)
+        assert np.all(rel_err(got, xd) < 1e-13), (got, xd)
+
+
+@pytest.mark.parametrize("name,ptype", [("open_loop_dt0p001.npz", "rc_plane"), ("open_loop_dt0p01.npz", "rc_plane"),
+                                        ("open_loop_cessna_dt0p01.npz", "cessna"), ("stress_dt0p01.npz", "rc_plane")])
+def test_open_loop_trajectories(oracle, name, ptype):
+    g = load_golden(name)
+    P = aircraft_params_for(ptype).to_block()
+    dt, steps, every = float(g["dt"]), int(g["steps"]), int(g["every"])
+    worst = 0.0
+    for i in range(g["x0"].shape[0]):
+        x = g["x0"][i].copy()
+        u = oracle.clip_controls(g["ctrl"][i])
+        assert np.all(rel_err(oracle.derived(x), g["derived"][i, 0], angle_cols=(3,)) < 1e-12)
+        for k in range(1, steps + 1):
+            assert oracle.rk4_step(P, x, u, dt) == 0
+            if k % every == 0:
+                e = rel_err(x, g["traj"][i, k // every], STATE_ANGLE_COLS).max()
+                worst = max(worst, e)
+                ed = rel_err(oracle.derived(x), g["derived"][i, k // every], angle_cols=(3,)).max()
+                worst = max(worst, ed)
+    # libm vs NumPy's SIMD sin/cos differ in the last ulp; open loop is not chaotic
+    assert worst < 1e-9, worst
+
+
+def test_backend_substepping(oracle):
+    g = load_golden("open_loop_backend_dt0p02.npz")
+    P = AircraftParams().to_block()
+    steps, every = int(g["steps"]), int(g["every"])
+    for i in range(g["x0"].shape[0]):
+        x = g["x0"][i].copy()
+        u = oracle.clip_controls(g["ctrl"][i])
+        for k in range(1, steps + 1):
+            assert oracle.backend_step(P, x, u, float(g["dt"]), float(g["dt_physics"])) == 20
+            if k % every == 0:
+                assert rel_err(x, g["traj"][i, k // every], STATE_ANGLE_COLS).max() < 1e-9
+    c = load_golden("substep_counts.npz")
+    for (dt, dtp), n in zip(c["cases"], c["nsub"]):
+        assert oracle.lib.orc_num_substeps(dt, dtp) == n
+
+
+def test_invalid_dt_is_rejected(oracle):
+    P = AircraftParams().to_block()
+    x = np.zeros(12); x[3] = 20.0
+    u = np.zeros(4)
+    assert oracle.rk4_step(P, x, u, 1e-6) == -1       # dt <= min_timestep (simplified_6dof.py:241)
+    assert oracle.rk4_step(P, x, u, 1.5) == -1
+    assert oracle.rk4_step(P, x, u, 1.0) == 0
+
+
+def test_pid_bit_exact_sequences(oracle):
+    g = load_golden("pid_sequences.npz")
+    for s in range(g["cfg"].shape[0]):
+        cfg = np.ascontiguousarray(g["cfg"][s])
+        st = np.zeros(3, np.float32)
+        for t in range(g["setpoint"].shape[1]):
+            out = oracle.lib.orc_pid_compute(oracle.fp(cfg), oracle.fp(st), float(g["setpoint"][s, t]),
+                                             float(g["measurement"][s, t]), float(g["dt"][s, t]))
+            assert np.float32(out) == g["output"][s, t], (s, t)
+            assert st[0] == g["integral"][s, t] and st[2] == g["derivative"][s, t], (s, t)
+
+
+def _pid(oracle, cfg):
+    st = np.zeros(3, np.float32)
+    cfg = np.asarray(cfg, np.float32)
+    return lambda sp, m, dt: float(oracle.lib.orc_pid_compute(oracle.fp(cfg), oracle.fp(st), sp, m, dt)), st
+
+
+def test_pid_known_answers(oracle):
+    """The exact values the reference's own tests/test_pid_bindings.py pins."""
+    dflt = [0, 0, 0, -1, 1, -10, 10, 0.1]
+    f, _ = _pid(oracle, [2.0, 0, 0] + dflt[3:])               # P-only saturation :89-102
+    assert f(10.0, 0.0, 0.01) == 1.0 and f(-10.0, 0.0, 0.01) == -1.0
+    f, st = _pid(oracle, [0, 1.0, 0, -100, 100, -10, 10, 0.1])  # I accumulation :104-123
+    for _ in range(10):
+        f(1.0, 0.0, 0.1)
+    assert abs(st[0] - 1.0) < 1e-5
+    f, st = _pid(oracle, [0, 1.0, 0, -100, 100, -5, 5, 0.1])    # anti-windup :175-190
+    for _ in range(100):
+        f(10.0, 0.0, 0.1)
+    assert st[0] == 5.0
+    f, st = _pid(oracle, [0, 0, 1.0, -100, 100, -10, 10, 1.0])  # derivative (5-0)/0.1 = 50 with alpha=1 :192-209
+    f(0.0, 0.0, 0.1)
+    assert abs(f(5.0, 0.0, 0.1) - 50.0) < 1e-3
+
+
+def test_wrap_angle(oracle):
+    for a in np.linspace(-20, 20, 4001):
+        want = (a + np.pi) % (2 * np.pi) - np.pi
+        assert oracle.lib.orc_wrap_angle(a) == want
+    assert oracle.lib.orc_wrap_angle(np.pi) == -np.pi        # [-pi, pi)
+
+
+def _tables(flight=True, guidance="PP"):
+    fc = cfgmod.load_controller_config("cascaded_pid.yaml") if flight else None
+    return (cfgmod.pid_table(ControllerConfig(), fc),
+            cfgmod.cascade_consts(ControllerConfig(), fc, guidance_type=guidance))
+
+
+def test_agents_level_by_level(oracle):
+    g = load_golden("agents.npz")
+    T = g["x"].shape[0]
+    tol = 2e-6   # fp32 PID outputs: 1 float ulp if an fp64 ulp straddles a float rounding boundary
+    for j, dt in enumerate((0.01, 0.001)):          # rate agent; dt=None falls back to rate_loop_dt=0.001
+        pc, Cc = _tables(False)
+        ps = np.zeros((L.FD_NPID, L.FD_NPS), np.float32)
+        for t in range(T):
+            out = np.zeros(4)
+            oracle.lib.orc_rate_agent(oracle.fp(pc), oracle.fp(ps), oracle.dp(Cc), oracle.dp(g["cmd_rate"][t].copy()),
+                                      float(g["throttle"][t]), oracle.dp(g["x"][t].copy()), dt, oracle.dp(out))
+            assert np.abs(out - g["out_rate"][j, t]).max() < tol, (j, t)
+    pc, Cc = _tables(False)
+    ps = np.zeros((L.FD_NPID, L.FD_NPS), np.float32)
+    for t in range(T):                              # attitude
+        out = np.zeros(4)
+        oracle.lib.orc_attitude_agent(oracle.fp(pc), oracle.fp(ps), oracle.dp(Cc), oracle.dp(g["cmd_att"][t].copy()), 1,
+                                      float(g["throttle"][t]), oracle.dp(g["x"][t].copy()), 0.01, oracle.dp(out))
+        assert np.abs(out - g["out_att"][t]).max() < tol, t
+    for j, flight in enumerate((True, False)):      # HSA with YAML config / with defaults
+        pc, Cc = _tables(flight)
+        ps = np.zeros((L.FD_NPID, L.FD_NPS), np.float32)
+        for t in range(T):
+            out = np.zeros(4)
+            oracle.lib.orc_hsa_agent(oracle.fp(pc), oracle.fp(ps), oracle.dp(Cc), oracle.dp(g["cmd_hsa"][t].copy()),
+                                     oracle.dp(g["x"][t].copy()), oracle.dp(g["derived"][t].copy()), 0.01, oracle.dp(out))
+            assert np.abs(out - g["out_hsa"][j, t]).max() < tol, (j, t)
+    for j, gd in enumerate(("PP", "LOS", "XX")):    # waypoint guidance laws
+        pc, Cc = _tables(True, gd)
+        ps = np.zeros((L.FD_NPID, L.FD_NPS), np.float32)
+        for t in range(T):
+            out = np.zeros(4)
+            oracle.lib.orc_waypoint_agent(oracle.fp(pc), oracle.fp(ps), oracle.dp(Cc), oracle.dp(g["wps"][t].copy()),
+                                          oracle.dp(g["x"][t].copy()), oracle.dp(g["derived"][t].copy()), 0.01,
+                                          oracle.dp(out))
+            assert np.abs(out - g["out_wp"][j, t]).max() < tol, (gd, t)
+
+
+def test_cfg1_rate_pid_closed_loop(oracle):
+    """examples/01_hello_controls.py loop: RateAgent(dt=0.01) -> backend.step(0.01) (10 sub-steps), 500 steps."""
+    g = load_golden("cfg1_rate_pid.npz")
+    P = AircraftParams().to_block()
+    pc, Cc = _tables(False)
+    ps = np.zeros((L.FD_NPID, L.FD_NPS), np.float32)
+    x = g["x0"].copy()
+    cmd = g["cmd"]
+    worst = 0.0
+    for i in range(int(g["steps"])):
+        surf = np.zeros(4)
+        oracle.lib.orc_rate_agent(oracle.fp(pc), oracle.fp(ps), oracle.dp(Cc), oracle.dp(cmd[:3].copy()), float(cmd[3]),
+                                  oracle.dp(x), 0.01, oracle.dp(surf))
+        assert np.abs(surf - g["surfaces"][i]).max() < 1e-5, i
+        oracle.backend_step(P, x, oracle.clip_controls(surf), 0.01, 0.001)
+        worst = max(worst, rel_err(x, g["traj"][i], STATE_ANGLE_COLS).max())
+    # saturating, limit-cycling loop: a 1-ulp libm difference is amplified; horizon 500 steps
+    assert worst < 1e-6, worst
+    assert abs(np.degrees(x[9]) + 129.185359) < 1e-3       # SURVEY §8a recorded value at step 499
+
+
+def test_cfg3_waypoint_square(oracle):
+    """examples/03_waypoint_square_demo.py loop: 5-level cascade, PP guidance, one RK4 per 10 ms."""
+    g = load_golden("cfg3_waypoint_square.npz")
+    P = AircraftParams().to_block()
+    fc = cfgmod.load_controller_config("cascaded_pid.yaml")
+    pc = cfgmod.pid_table(ControllerConfig(), fc)
+    Cc = cfgmod.cascade_consts(ControllerConfig(), fc, guidance_type="PP", acceptance_radius=float(g["radius"]))
+    wps = np.ascontiguousarray(g["waypoints"], np.float64)
+    ps = np.zeros((L.FD_NPID, L.FD_NPS), np.float32)
+    x = g["x0"].copy()
+    idx = np.zeros(1, np.int32)
+    reached = np.zeros(1, np.int32)
+    events, k, worst = [], 0, 0.0
+    while k < 20000:
+        if k % 10 == 0:
+            worst = max(worst, rel_err(x, g["traj"][k // 10], STATE_ANGLE_COLS).max())
+            assert g["wp_index"][k // 10] == idx[0]
+        surf = np.zeros(4)
+        done = oracle.lib.orc_cascade_step(oracle.dp(P), oracle.fp(pc), oracle.fp(ps), oracle.dp(Cc), oracle.dp(wps),
+                                           len(wps), oracle.ip(idx), oracle.dp(x), float(g["dt"]), oracle.dp(surf),
+                                           oracle.ip(reached))
+        if reached[0]:
+            events.append(k)
+        if done:
+            break
+        if k % 10 == 0:
+            assert np.abs(surf - g["surfaces"][k // 10]).max() < 1e-4, k
+        k += 1
+    assert k == int(g["n_steps"])
+    assert events == [int(e) for e in g["events"][:, 0]]
+    assert rel_err(x, g["final"], STATE_ANGLE_COLS).max() < 1e-6
+    assert worst < 1e-6, worst
+
+
+def test_rewards_sequence(oracle):
+    g = load_golden("rewards_sequence.npz")
+    e = np.zeros(L.FD_NE)
+    e2 = np.zeros(L.FD_NE)
+    cmd = g["cmd"].copy()
+    for t in range(g["errs"].shape[0]):
+        e[L.FD_E_PREV_AIL:L.FD_E_PREV_THR + 1] = g["prev_actions"][t]
+        comps = np.zeros(5)
+        fl = g["flight"][t]
+        r = oracle.lib.orc_tracking_reward(oracle.dp(e), oracle.dp(g["errs"][t].copy()), oracle.dp(g["actions"][t].copy()),
+                                           fl[0], fl[1], fl[2], fl[3], oracle.dp(comps))
+        assert abs(r - g["tracking_reward"][t]) < 1e-14 and np.abs(comps - g["components"][t]).max() < 1e-14, t
+        s = oracle.lib.orc_settle_bonus(oracle.dp(e2), oracle.dp(g["errs"][t].copy()), oracle.dp(cmd), 0.02)
+        assert s == g["settle_reward"][t] and e2[L.FD_E_IS_SETTLED] == g["settled"][t], t
+
+
+def test_samplers_match_reference_streams():
+    g = load_golden("samplers.npz")
+    for seed in (0, 42, 43, 1234):
+        es = samplers.FlightEnvelopeSampler(rng_seed=seed)
+        for row in g[f"ic_seed{seed}"]:
+            d = es.sample()
+            assert np.array_equal(row, [d["airspeed"], d["altitude"], *d["attitude"], *d["angular_rate"]])
+        for diff in ("easy", "medium", "hard"):
+            rng = np.random.RandomState(seed)
+            cg = samplers.RateCommandGenerator(difficulty=diff, rng_seed=seed)
+            for row in g[f"step_{diff}_seed{seed}"]:
+                assert np.array_equal(row, cg.generate_step_command(num_axes=rng.choice([1, 2, 3]))[0])
+            cg = samplers.RateCommandGenerator(difficulty=diff, rng_seed=seed)
+            for row in g[f"ramp_{diff}_seed{seed}"]:
+                assert np.array_equal(row, cg.generate_ramp_command()[1])
+            cg = samplers.RateCommandGenerator(difficulty=diff, rng_seed=seed)
+            for row in g[f"sine_{diff}_seed{seed}"]:
+                f, a, _ = cg.generate_sine_command()
+                assert np.array_equal(row, [f, *a])
+            cg = samplers.RateCommandGenerator(difficulty=diff, rng_seed=seed)
+            for row in g[f"rw_{diff}_seed{seed}"]:
+                assert np.array_equal(row, cg.generate_random_walk(dt=0.02)[0])
+
+
+def _run_oracle_episode(oracle, P, EC, streams, actions, n_steps, rw=False):
+    x, e, ei = np.zeros(12), np.zeros(L.FD_NE), np.zeros(L.FD_NEI, np.int32)
+    obs = np.zeros(18, np.float32)
+    oracle.lib.orc_env_reset(oracle.dp(EC), oracle.dp(x), oracle.dp(e), oracle.ip(ei), oracle.dp(streams.next_record()),
+                             oracle.fp(obs))
+    out = dict(obs=[obs.copy()], rewards=[], flags=[], states=[], cmds=[])
+    r, te, tr = np.zeros(1), np.zeros(1, np.int32), np.zeros(1, np.int32)
+    for k in range(n_steps):
+        a = np.ascontiguousarray(actions[k] if actions.ndim == 2 else actions, np.float32)
+        d = streams.random_walk_delta(float(EC[L.FD_EC_DT])) if rw else np.zeros(3)
+        oracle.lib.orc_env_step(oracle.dp(P), oracle.dp(EC), oracle.dp(x), oracle.dp(e), oracle.ip(ei), oracle.fp(a),
+                                oracle.dp(np.ascontiguousarray(d)), oracle.fp(obs), oracle.dp(r), oracle.ip(te), oracle.ip(tr))
+        out["obs"].append(obs.copy()); out["rewards"].append(r[0]); out["states"].append(x.copy())
+        out["flags"].append([te[0], tr[0], int(e[L.FD_E_IS_SETTLED])]); out["cmds"].append(e[L.FD_E_CMD_P:L.FD_E_CMD_R + 1].copy())
+        if te[0] or tr[0]:
+            break
+    return {k: np.array(v) for k, v in out.items()}, e
+
+
+def test_env_survey_episode(oracle):
+    """RateControlEnv(easy, step, rng_seed=42).reset(seed=42), constant action (0.1,0,0,0.6): SURVEY §8a values."""
+    g = load_golden("env_easy_step_seed42_const.npz")
+    P = AircraftParams().to_block()
+    EC = samplers.env_consts("easy", 10, 0.02, "step")
+    st = samplers.EpisodeStreams("easy", "step", 42)
+    st.reseed_env_rng(42)
+    ep, e = _run_oracle_episode(oracle, P, EC, st, g["actions"], 600)
+    assert np.allclose(ep["cmds"][0], [-0.90996233, -0.79713236, -0.34282152], atol=1e-8)
+    assert len(ep["rewards"]) == 150 and ep["flags"][-1, 0] == 1 and ep["flags"][-1, 1] == 0
+    assert abs(ep["rewards"].sum() + 15.188049) < 1e-5 and abs(e[L.FD_E_EP_RETURN] - ep["rewards"].sum()) < 1e-9
+    assert np.abs(ep["rewards"] - g["rewards"]).max() < 1e-9
+    assert np.array_equal(ep["flags"], g["flags"].astype(int))
+    assert rel_err(ep["obs"], g["obs"]).max() < 1e-6          # float32 observations
+    assert rel_err(ep["states"], g["states"], STATE_ANGLE_COLS).max() < 1e-9
+
+
+@pytest.mark.parametrize("name,diff,ct,seed", [
+    ("env_medium_step_seed7_rand.npz", "medium", "step", 7),
+    ("env_easy_step_seed3_pid.npz", "easy", "step", 3),
+    ("env_medium_step_seed11_pid.npz", "medium", "step", 11),
+    ("env_hard_random_seed5_pid.npz", "hard", "random", 5),
+    ("env_medium_ramp_seed9_pid.npz", "medium", "ramp", 9),
+    ("env_medium_sine_seed13_pid.npz", "medium", "sine", 13)])
+def test_env_episodes(oracle, name, diff, ct, seed):
+    """Replay the recorded actions; includes a second episode on un-reseeded sampler streams (auto-reset path)."""
+    g = load_golden(name)
+    P = AircraftParams().to_block()
+    EC = samplers.env_consts(diff, 10.0, 0.02, ct)
+    st = samplers.EpisodeStreams(diff, ct, seed)
+    st.reseed_env_rng(seed)
+    prefixes = ["ep0_", "ep1_"] if "ep0_obs" in g.files else [""]
+    for pre in prefixes:
+        acts = g[pre + "actions"]
+        ep, _ = _run_oracle_episode(oracle, P, EC, st, acts, len(acts), rw=(ct == "random"))
+        assert len(ep["rewards"]) == len(g[pre + "rewards"])
+        assert np.array_equal(ep["flags"], g[pre + "flags"].astype(int))
+        assert np.abs(ep["cmds"] - g[pre + "cmds"]).max() < 1e-12
+        assert np.abs(ep["rewards"] - g[pre + "rewards"]).max() < 1e-7
+        assert rel_err(ep["obs"], g[pre + "obs"]).max() < 1e-6
+        assert rel_err(ep["states"], g[pre + "states"], STATE_ANGLE_COLS).max() < 1e-8
