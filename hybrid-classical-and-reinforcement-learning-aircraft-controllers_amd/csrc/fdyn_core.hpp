@@ -1,0 +1,518 @@
+// fdyn_core.hpp -- per-aircraft device code for gfx950 (MI355X): 6-DOF dynamics + RK4, fp32 PID, the
+// 5-level cascade and the rate-control env step.  One lane == one aircraft; everything lives in registers.
+//
+// Precision is a template pair <S, T>:
+//   S  = type the 12-word state is STORED and ACCUMULATED in (and the fp64/fp32 "glue" of agents / rewards)
+//   T  = type one dynamics evaluation is COMPUTED in
+//   <double,double> "f64"   : the parity variant (the reference is float64, simplified_6dof.py:173)
+//   <double,float>  "mixed" : fp32 derivative evaluations, fp64 state accumulate (drift ~1e-6)
+//   <float,float>   "f32"   : pure fp32 throughput variant
+// The PID is always fp32 with contraction off: bit-faithful to cpp/src/pid_controller.cpp:24-60.
+//
+// Reference citations are relative to the reference root; layouts in include/fdyn_layout.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/fdyn_layout.h"
+
+namespace fdyn {
+
+#define FD_DEV __device__ __forceinline__
+
+// ----- scalar math traits ---------------------------------------------------------------------------------
+template <typename T> struct M;
+template <> struct M<double> {
+    static FD_DEV double sin(double x) { return ::sin(x); }
+    static FD_DEV double cos(double x) { return ::cos(x); }
+    static FD_DEV void sincos(double x, double& s, double& c) { ::sincos(x, &s, &c); }
+    static FD_DEV double tan(double x) { return ::tan(x); }
+    static FD_DEV double atan2(double y, double x) { return ::atan2(y, x); }
+    static FD_DEV double asin(double x) { return ::asin(x); }
+    static FD_DEV double sqrt(double x) { return ::sqrt(x); }
+    static FD_DEV double exp(double x) { return ::exp(x); }
+    static FD_DEV double abs(double x) { return ::fabs(x); }
+    static FD_DEV double rint(double x) { return ::rint(x); }
+    static FD_DEV double fmod(double x, double y) { return ::fmod(x, y); }
+    static FD_DEV bool finite(double x) { return ::isfinite(x); }
+};
+template <> struct M<float> {
+    static FD_DEV float sin(float x) { return ::sinf(x); }
+    static FD_DEV float cos(float x) { return ::cosf(x); }
+    static FD_DEV void sincos(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
+    static FD_DEV float tan(float x) { return ::tanf(x); }
+    static FD_DEV float atan2(float y, float x) { return ::atan2f(y, x); }
+    static FD_DEV float asin(float x) { return ::asinf(x); }
+    static FD_DEV float sqrt(float x) { return ::sqrtf(x); }
+    static FD_DEV float exp(float x) { return ::expf(x); }
+    static FD_DEV float abs(float x) { return ::fabsf(x); }
+    static FD_DEV float rint(float x) { return ::rintf(x); }
+    static FD_DEV float fmod(float x, float y) { return ::fmodf(x, y); }
+    static FD_DEV bool finite(float x) { return ::isfinite(x); }
+};
+
+// Python / NumPy semantics the reference relies on
+template <typename T> FD_DEV T clipv(T x, T lo, T hi) { return x < lo ? lo : (x > hi ? hi : x); }   // np.clip, NaN stays
+template <typename T> FD_DEV T pymax(T a, T b) { return b > a ? b : a; }                            // max(a, b)
+template <typename T> FD_DEV T pymin(T a, T b) { return b < a ? b : a; }                            // min(a, b)
+template <typename T> FD_DEV T signv(T x) { return x > T(0) ? T(1) : (x < T(0) ? T(-1) : x); }      // np.sign (0->0, NaN->NaN)
+
+#define FD_PI 3.14159265358979323846
+template <typename T> FD_DEV T deg2rad(double d) { return T(d * (FD_PI / 180.0)); }   // constant-folded on the host side
+
+// (a + pi) % (2 pi) - pi with Python floor-mod: [-pi, pi)     controllers/utils/pid_utils.py:65
+template <typename T> FD_DEV T wrap_angle(T a)
+{
+    const T b = T(2.0 * FD_PI);
+    T m = M<T>::fmod(a + T(FD_PI), b);
+    if (m < T(0)) m += b;
+    return m - T(FD_PI);
+}
+
+// ----- aircraft parameter block, converted to the compute type and held in registers ---------------------
+template <typename T> struct Params {
+    T mass, inv_mass, ixx, iyy, izz, S, b, c;
+    T cl_0, cl_alpha, cd_0, cd_alpha2, cl_de, cm_de, cy_dr, cn_dr, cl_da, cm_alpha, cn_beta, cl_beta;
+    T damp_roll, damp_pitch, damp_yaw, max_thrust, half_rho, g;
+    T min_airspeed, min_u, max_de, max_da, max_dr, thrust_zero_v;
+    T max_alpha, max_pitch, max_acc, max_ang_acc;
+
+    // `blk` points at one FD_NP-word block staged in LDS (stored as double; narrowed here once per launch)
+    FD_DEV void load(const double* blk)
+    {
+        mass = T(blk[FD_P_MASS]); inv_mass = T(1.0) / mass;                     // simplified_6dof.py:455
+        ixx = T(blk[FD_P_IXX]); iyy = T(blk[FD_P_IYY]); izz = T(blk[FD_P_IZZ]);
+        S = T(blk[FD_P_WING_AREA]); b = T(blk[FD_P_WING_SPAN]); c = T(blk[FD_P_CHORD]);
+        cl_0 = T(blk[FD_P_CL_0]); cl_alpha = T(blk[FD_P_CL_ALPHA]); cd_0 = T(blk[FD_P_CD_0]);
+        cd_alpha2 = T(blk[FD_P_CD_ALPHA2]); cl_de = T(blk[FD_P_CL_ELEVATOR]); cm_de = T(blk[FD_P_CM_ELEVATOR]);
+        cy_dr = T(blk[FD_P_CY_RUDDER]); cn_dr = T(blk[FD_P_CN_RUDDER]); cl_da = T(blk[FD_P_CL_AILERON]);
+        cm_alpha = T(blk[FD_P_CM_ALPHA]); cn_beta = T(blk[FD_P_CN_BETA]); cl_beta = T(blk[FD_P_CL_BETA]);
+        damp_roll = T(blk[FD_P_DAMPING_ROLL]); damp_pitch = T(blk[FD_P_DAMPING_PITCH]);
+        damp_yaw = T(blk[FD_P_DAMPING_YAW]); max_thrust = T(blk[FD_P_MAX_THRUST]);
+        half_rho = T(0.5 * blk[FD_P_AIR_DENSITY]); g = T(blk[FD_P_GRAVITY]);
+        min_airspeed = T(blk[FD_P_MIN_AIRSPEED_AERO]); min_u = T(blk[FD_P_MIN_U_VELOCITY]);
+        max_de = T(blk[FD_P_MAX_ELEVATOR_RAD]); max_da = T(blk[FD_P_MAX_AILERON_RAD]);
+        max_dr = T(blk[FD_P_MAX_RUDDER_RAD]); thrust_zero_v = T(blk[FD_P_THRUST_ZERO_VELOCITY]);
+        max_alpha = T(blk[FD_P_MAX_ALPHA_RAD]); max_pitch = T(blk[FD_P_MAX_PITCH_RAD]);
+        max_acc = T(blk[FD_P_MAX_ACCELERATION]); max_ang_acc = T(blk[FD_P_MAX_ANGULAR_ACCELERATION]);
+    }
+};
+
+// limits applied to the stored state after each RK4 step (in the storage type)
+template <typename S> struct Limits {
+    S max_vel, max_rate, max_pitch, min_dt, max_dt;
+    FD_DEV void load(const double* blk)
+    {
+        max_vel = S(blk[FD_P_MAX_VELOCITY]); max_rate = S(blk[FD_P_MAX_RATE_RAD]);
+        max_pitch = S(blk[FD_P_MAX_PITCH_RAD]); min_dt = S(blk[FD_P_MIN_TIMESTEP]); max_dt = S(blk[FD_P_MAX_TIMESTEP]);
+    }
+};
+
+// controls after set_controls' clip (simplified_6dof.py:221-226), pre-multiplied into radians per launch
+template <typename T> struct Controls {
+    T de_rad, da_rad, dr_rad, throttle;
+    template <typename S> FD_DEV void set(const Params<T>& P, S elevator, S aileron, S rudder, S thr)
+    {
+        de_rad = T(clipv<S>(elevator, S(-1), S(1))) * P.max_de;     // :383
+        da_rad = T(clipv<S>(aileron, S(-1), S(1))) * P.max_da;      // :415
+        dr_rad = T(clipv<S>(rudder, S(-1), S(1))) * P.max_dr;       // :389
+        throttle = T(clipv<S>(thr, S(0), S(1)));
+    }
+};
+
+// ----- one evaluation of the equations of motion: simplified_6dof.py:333-503 ----------------------------
+template <typename T>
+FD_DEV void dynamics(const Params<T>& P, const Controls<T>& C, const T (&x)[FD_NX], T (&xd)[FD_NX])
+{
+    const T u = x[3], v = x[4], w = x[5], theta = x[7];
+    const T p = x[9], q = x[10], r = x[11];
+    T sin_phi, cos_phi, sin_theta, cos_theta, sin_psi, cos_psi;
+    M<T>::sincos(x[6], sin_phi, cos_phi);
+    M<T>::sincos(theta, sin_theta, cos_theta);
+    M<T>::sincos(x[8], sin_psi, cos_psi);
+
+    const T airspeed = M<T>::sqrt(u * u + v * v + w * w);                               // :363
+    const T safe_airspeed = pymax(airspeed, P.min_airspeed);                            // :364
+    const T au = M<T>::abs(u);
+    const T u_safe = au > T(1e-6) ? pymax(au, P.min_u) * signv(u) : P.min_u;            // :368
+    T alpha = M<T>::atan2(w, u_safe);
+    alpha = clipv(alpha, -P.max_alpha, P.max_alpha);                                    // :370
+    T sin_alpha, cos_alpha;
+    M<T>::sincos(alpha, sin_alpha, cos_alpha);
+    const T beta = M<T>::asin(clipv(v / safe_airspeed, T(-1), T(1)));                   // :376
+    const T q_dyn = P.half_rho * (airspeed * airspeed);                                 // :379 (unclamped V)
+
+    const T cl = P.cl_0 + P.cl_alpha * alpha + P.cl_de * C.de_rad;                      // :384-390
+    const T cd = P.cd_0 + P.cd_alpha2 * (alpha * alpha);
+    const T cy = P.cy_dr * C.dr_rad;
+    const T q_S = q_dyn * P.S;
+    const T lift = q_S * cl, drag = q_S * cd, side_force = q_S * cy;
+    const T fx_aero = -drag * cos_alpha + lift * sin_alpha;                             // :397-399
+    const T fz_aero = -drag * sin_alpha - lift * cos_alpha;
+
+    const T thrust_factor = pymax(T(0), T(1) - airspeed / P.thrust_zero_v);             // :403
+    const T thrust = P.max_thrust * C.throttle * thrust_factor;
+
+    const T fx = fx_aero + thrust + (-P.g * sin_theta) * P.mass;                        // :409-411
+    const T fy = side_force + (P.g * cos_theta * sin_phi) * P.mass;
+    const T fz = fz_aero + (P.g * cos_theta * cos_phi) * P.mass;
+
+    const T half_span_over_V = P.b / (T(2) * safe_airspeed);                            // :416-417
+    const T half_chord_over_V = P.c / (T(2) * safe_airspeed);
+    const T l_moment = q_S * P.b * (P.cl_da * C.da_rad + P.damp_roll * p * half_span_over_V + P.cl_beta * beta);
+    const T m_moment = q_S * P.c * (P.cm_de * C.de_rad + P.cm_alpha * alpha + P.damp_pitch * q * half_chord_over_V);
+    const T n_moment = q_S * P.b * (P.cn_dr * C.dr_rad + P.damp_yaw * r * half_span_over_V + P.cn_beta * beta);
+
+    const T sps = sin_phi * sin_theta, cps = cos_phi * sin_theta;                       // :440-452
+    xd[0] = cos_theta * cos_psi * u + (sps * cos_psi - cos_phi * sin_psi) * v + (cps * cos_psi + sin_phi * sin_psi) * w;
+    xd[1] = cos_theta * sin_psi * u + (sps * sin_psi + cos_phi * cos_psi) * v + (cps * sin_psi - sin_phi * cos_psi) * w;
+    xd[2] = -sin_theta * u + sin_phi * cos_theta * v + cos_phi * cos_theta * w;
+
+    xd[3] = fx * P.inv_mass - q * w + r * v;                                            // :455-460
+    xd[4] = fy * P.inv_mass - r * u + p * w;
+    xd[5] = fz * P.inv_mass - p * v + q * u;
+
+    const T theta_safe = clipv(theta, -P.max_pitch, P.max_pitch);                       // :463-471
+    T cos_ts, tan_ts;
+    if (theta_safe == theta) { cos_ts = cos_theta; } else { cos_ts = M<T>::cos(theta_safe); }
+    tan_ts = M<T>::tan(theta_safe);
+    xd[6] = p + sin_phi * tan_ts * q + cos_phi * tan_ts * r;
+    xd[7] = cos_phi * q - sin_phi * r;
+    xd[8] = (sin_phi * q + cos_phi * r) / cos_ts;
+
+    xd[9] = (l_moment - (P.izz - P.iyy) * q * r) / P.ixx;                               // :474-482
+    xd[10] = (m_moment - (P.ixx - P.izz) * p * r) / P.iyy;
+    xd[11] = (n_moment - (P.iyy - P.ixx) * p * q) / P.izz;
+
+#pragma unroll
+    for (int i = 9; i < 12; ++i) xd[i] = clipv(xd[i], -P.max_ang_acc, P.max_ang_acc);  // :485-490
+#pragma unroll
+    for (int i = 3; i < 6; ++i) xd[i] = clipv(xd[i], -P.max_acc, P.max_acc);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) xd[i] = M<T>::finite(xd[i]) ? xd[i] : T(0);            // :496-501 (branch-free)
+}
+
+// roll / yaw re-wrap of the stored state (simplified_6dof.py:266,270).  The f64 variant keeps the
+// reference's atan2(sin, cos) form; the fp32-compute variants use the equivalent range reduction.
+template <typename S, typename T> FD_DEV S wrap_state_angle(S a)
+{
+    if constexpr (sizeof(T) == 8) {
+        S s, c;
+        M<S>::sincos(a, s, c);
+        return M<S>::atan2(s, c);
+    } else {
+        return a - S(2.0 * FD_PI) * M<S>::rint(a * S(1.0 / (2.0 * FD_PI)));
+    }
+}
+
+// ----- Simplified6DOF.step: RK4 + post-clamps, simplified_6dof.py:247-291 --------------------------------
+template <typename S, typename T>
+FD_DEV void rk4_step(const Params<T>& P, const Limits<S>& Lm, const Controls<T>& C, S (&x)[FD_NX], S dt)
+{
+    T xt[FD_NX], k[FD_NX];
+    S acc[FD_NX];
+    const T hdt = T(S(0.5) * dt), fdt = T(dt);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) xt[i] = T(x[i]);
+    dynamics<T>(P, C, xt, k);                                        // k1
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { acc[i] = S(k[i]); xt[i] = T(x[i] + S(hdt) * S(k[i])); }
+    dynamics<T>(P, C, xt, k);                                        // k2
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { acc[i] += S(2) * S(k[i]); xt[i] = T(x[i] + S(hdt) * S(k[i])); }
+    dynamics<T>(P, C, xt, k);                                        // k3
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { acc[i] += S(2) * S(k[i]); xt[i] = T(x[i] + S(fdt) * S(k[i])); }
+    dynamics<T>(P, C, xt, k);                                        // k4
+    const S dt6 = dt / S(6);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) x[i] = x[i] + dt6 * (acc[i] + S(k[i]));              // :253
+
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {                                                      // :258 nan_to_num
+        const S v = x[i];
+        x[i] = (v != v) ? S(0) : (M<S>::finite(v) ? v : (v > S(0) ? S(10000) : S(-10000)));
+    }
+#pragma unroll
+    for (int i = 3; i < 6; ++i) x[i] = clipv(x[i], -Lm.max_vel, Lm.max_vel);          // :262
+    x[6] = wrap_state_angle<S, T>(x[6]);                                               // :266
+    x[7] = clipv(x[7], -Lm.max_pitch, Lm.max_pitch);                                   // :268
+    x[8] = wrap_state_angle<S, T>(x[8]);                                               // :270
+#pragma unroll
+    for (int i = 9; i < 12; ++i) x[i] = clipv(x[i], -Lm.max_rate, Lm.max_rate);       // :273
+    if (-x[2] < S(0)) {                                                                // :276-283 ground clamp
+        x[2] = S(0);
+        x[5] = x[5] > S(0) ? x[5] : S(0);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) x[i] = M<S>::finite(x[i]) ? x[i] : S(0);              // :286-291
+}
+
+// ----- get_state's derived scalars: simplified_6dof.py:295-331 + _body_to_ned :505-530 -------------------
+template <typename S> struct Derived { S airspeed, altitude, ground_speed, heading; };
+template <typename S> FD_DEV Derived<S> derived(const S (&x)[FD_NX])
+{
+    Derived<S> d;
+    const S u = x[3], v = x[4], w = x[5];
+    S sphi, cphi, sth, cth, spsi, cpsi;
+    M<S>::sincos(x[6], sphi, cphi);
+    M<S>::sincos(x[7], sth, cth);
+    M<S>::sincos(x[8], spsi, cpsi);
+    d.airspeed = M<S>::sqrt(u * u + v * v + w * w);
+    d.altitude = -x[2];
+    const S vn = (cth * cpsi) * u + (sphi * sth * cpsi - cphi * spsi) * v + (cphi * sth * cpsi + sphi * spsi) * w;
+    const S ve = (cth * spsi) * u + (sphi * sth * spsi + cphi * cpsi) * v + (cphi * sth * spsi - sphi * cpsi) * w;
+    d.heading = M<S>::atan2(ve, vn);
+    d.ground_speed = M<S>::sqrt(vn * vn + ve * ve);
+    return d;
+}
+// airspeed / altitude only (what the env needs every step)
+template <typename S> FD_DEV void airspeed_altitude(const S (&x)[FD_NX], S& airspeed, S& altitude)
+{
+    airspeed = M<S>::sqrt(x[3] * x[3] + x[4] * x[4] + x[5] * x[5]);
+    altitude = -x[2];
+}
+
+// ----- fp32 PID: cpp/src/pid_controller.cpp:24-60, bit-faithful (no FMA contraction, same op order) ------
+struct PidCfg { float kp, ki, kd, out_min, out_max, int_min, int_max, alpha; };
+struct PidState { float integral, err_prev, dfilt; };
+
+FD_DEV float pid_clamp(float v, float lo, float hi)
+{   // std::max(min_val, std::min(value, max_val))   pid_controller.cpp:79-81
+    const float m = (hi < v) ? hi : v;
+    return (lo < m) ? m : lo;
+}
+
+FD_DEV float pid_compute(const PidCfg& c, PidState& s, float setpoint, float measurement, float dt)
+{
+#pragma clang fp contract(off)
+    const float error = setpoint - measurement;
+    const float p_term = c.kp * error;
+    float integral = s.integral + error * dt;
+    integral = pid_clamp(integral, c.int_min, c.int_max);
+    const float i_term = c.ki * integral;
+    const float derivative = (dt > 1e-6f) ? (error - s.err_prev) / dt : 0.0f;
+    const float dfilt = c.alpha * derivative + (1.0f - c.alpha) * s.dfilt;
+    const float d_term = c.kd * dfilt;
+    float out = p_term + i_term + d_term;
+    out = pid_clamp(out, c.out_min, c.out_max);
+    s.integral = integral; s.err_prev = error; s.dfilt = dfilt;
+    return out;
+}
+
+FD_DEV PidCfg load_pid_cfg(const float* t, int which)
+{
+    const float* r = t + which * FD_NPC;
+    return PidCfg{ r[FD_PC_KP], r[FD_PC_KI], r[FD_PC_KD], r[FD_PC_OUT_MIN], r[FD_PC_OUT_MAX],
+                   r[FD_PC_INT_MIN], r[FD_PC_INT_MAX], r[FD_PC_ALPHA] };
+}
+
+// ----- the cascade (glue in G = storage type, PIDs fp32) ----------------------------------------------------
+template <typename G> struct Surfaces { G elevator, aileron, rudder, throttle; };
+
+struct CascadePids { PidCfg cfg[FD_NPID]; };
+struct CascadeState { PidState s[FD_NPID]; };
+
+// controllers/rate_agent.py:92-122
+template <typename G>
+FD_DEV Surfaces<G> rate_agent(const PidCfg* cfg, PidState* st, const G* C, G p_cmd, G q_cmd, G r_cmd, G throttle,
+                              const G (&x)[FD_NX], G dt)
+{
+    p_cmd = clipv(p_cmd, -C[FD_C_MAX_ROLL_RATE], C[FD_C_MAX_ROLL_RATE]);
+    q_cmd = clipv(q_cmd, -C[FD_C_MAX_PITCH_RATE], C[FD_C_MAX_PITCH_RATE]);
+    r_cmd = clipv(r_cmd, -C[FD_C_MAX_YAW_RATE], C[FD_C_MAX_YAW_RATE]);
+    const float fdt = float(dt);
+    const float o_roll = pid_compute(cfg[FD_PID_RATE_ROLL], st[FD_PID_RATE_ROLL], float(p_cmd), float(x[9]), fdt);
+    const float o_pitch = pid_compute(cfg[FD_PID_RATE_PITCH], st[FD_PID_RATE_PITCH], float(q_cmd), float(x[10]), fdt);
+    const float o_yaw = pid_compute(cfg[FD_PID_RATE_YAW], st[FD_PID_RATE_YAW], float(r_cmd), float(x[11]), fdt);
+    Surfaces<G> s;
+    s.aileron = clipv(G(o_roll), G(-1), G(1));
+    s.elevator = clipv(-G(o_pitch), G(-1), G(1));      // INVERTED (rate_agent.py:111-112)
+    s.rudder = clipv(-G(o_yaw), G(-1), G(1));
+    s.throttle = clipv(throttle, G(0), G(1));
+    return s;
+}
+
+// controllers/attitude_agent.py:116-152
+template <typename G>
+FD_DEV Surfaces<G> attitude_agent(const PidCfg* cfg, PidState* st, const G* C, G roll_cmd, G pitch_cmd, G yaw_cmd,
+                                  bool has_yaw, G throttle, const G (&x)[FD_NX], G dt)
+{
+    roll_cmd = clipv(roll_cmd, -C[FD_C_MAX_ROLL], C[FD_C_MAX_ROLL]);
+    pitch_cmd = clipv(pitch_cmd, -C[FD_C_MAX_PITCH], C[FD_C_MAX_PITCH]);
+    yaw_cmd = has_yaw ? wrap_angle<G>(yaw_cmd) : G(0);
+    const G cur_yaw = wrap_angle<G>(x[8]);
+    const float fdt = float(dt);
+    const float o_r = pid_compute(cfg[FD_PID_ATT_ROLL], st[FD_PID_ATT_ROLL], float(roll_cmd), float(x[6]), fdt);
+    const float o_p = pid_compute(cfg[FD_PID_ATT_PITCH], st[FD_PID_ATT_PITCH], float(pitch_cmd), float(x[7]), fdt);
+    const float o_y = pid_compute(cfg[FD_PID_ATT_YAW], st[FD_PID_ATT_YAW], float(yaw_cmd), float(cur_yaw), fdt);
+    const G p_cmd = clipv(G(o_r), -C[FD_C_MAX_ROLL_RATE], C[FD_C_MAX_ROLL_RATE]);
+    const G q_cmd = clipv(G(o_p), -C[FD_C_MAX_PITCH_RATE], C[FD_C_MAX_PITCH_RATE]);
+    const G r_cmd = clipv(G(o_y), -C[FD_C_MAX_YAW_RATE], C[FD_C_MAX_YAW_RATE]);
+    return rate_agent<G>(cfg, st, C, p_cmd, q_cmd, r_cmd, throttle, x, dt);
+}
+
+// controllers/hsa_agent.py:149-229
+template <typename G>
+FD_DEV Surfaces<G> hsa_agent(const PidCfg* cfg, PidState* st, const G* C, G heading_cmd, G speed_cmd, G altitude_cmd,
+                             const G (&x)[FD_NX], const Derived<G>& d, G dt)
+{
+    const G heading_error = wrap_angle<G>(heading_cmd - d.heading);
+    const G virtual_setpoint = d.heading + heading_error;
+    const float fdt = float(dt);
+    G roll_angle = G(pid_compute(cfg[FD_PID_HEADING], st[FD_PID_HEADING], float(virtual_setpoint), float(d.heading), fdt));
+    roll_angle = clipv(roll_angle, -C[FD_C_MAX_BANK_RAD], C[FD_C_MAX_BANK_RAD]);
+
+    const G g = G(9.81), h = d.altitude, V = d.airspeed;                     // :173-185
+    const G E_specific = g * h + G(0.5) * (V * V);
+    const G E_specific_cmd = g * altitude_cmd + G(0.5) * (speed_cmd * speed_cmd);
+    const G E_balance = g * h - G(0.5) * (V * V);
+    const G E_balance_cmd = g * altitude_cmd - G(0.5) * (speed_cmd * speed_cmd);
+
+    const G thr_adj = G(pid_compute(cfg[FD_PID_ENERGY], st[FD_PID_ENERGY], float(E_specific_cmd), float(E_specific), fdt));
+    G throttle = clipv(C[FD_C_BASELINE_THROTTLE] + thr_adj, G(0), G(1));
+
+    G pitch_angle = G(pid_compute(cfg[FD_PID_BALANCE], st[FD_PID_BALANCE], float(E_balance_cmd), float(E_balance), fdt));
+    const G cos_roll = M<G>::cos(roll_angle);                                // :205-208
+    if (M<G>::abs(cos_roll) > G(0.01)) {
+        const G load_factor = G(1) / cos_roll;
+        pitch_angle += C[FD_C_LOAD_FACTOR_GAIN] * (load_factor - G(1));
+    }
+    pitch_angle = clipv(pitch_angle, -C[FD_C_MAX_PITCH_CMD_RAD], C[FD_C_MAX_PITCH_CMD_RAD]);
+    return attitude_agent<G>(cfg, st, C, roll_angle, pitch_angle, x[8], true, throttle, x, dt);
+}
+
+template <typename G> FD_DEV G wrap_pi(G a)
+{   // np.arctan2(np.sin(a), np.cos(a))
+    G s, c;
+    M<G>::sincos(a, s, c);
+    return M<G>::atan2(s, c);
+}
+
+// controllers/waypoint_agent.py:107-242 ; wp = {north, east, altitude, speed}
+template <typename G>
+FD_DEV Surfaces<G> waypoint_agent(const PidCfg* cfg, PidState* st, const G* C, const G* wp, const G (&x)[FD_NX],
+                                  const Derived<G>& d, G dt)
+{
+    const G e0 = wp[FD_WP_NORTH] - x[0], e1 = wp[FD_WP_EAST] - x[1];
+    const G hd = M<G>::sqrt(e0 * e0 + e1 * e1);
+    const int gtype = int(C[FD_C_GUIDANCE_TYPE]);
+    const G los = M<G>::atan2(e1, e0);
+    G heading_cmd = los;
+    if (gtype == FD_GUIDANCE_LOS) {                                          // :118-144
+        const G V = pymax(d.airspeed, G(10));
+        const G turn_radius = (V * V) / (G(9.81) * M<G>::tan(C[FD_C_LOS_MAX_BANK_RAD]));
+        const G heading_error = wrap_pi<G>(heading_cmd - d.heading);
+        const G anticipation = turn_radius * M<G>::abs(heading_error) / deg2rad<G>(90.0);
+        if (hd < anticipation && M<G>::abs(heading_error) > deg2rad<G>(20.0)) {
+            const G blend = G(1) - (hd / anticipation);
+            heading_cmd = wrap_pi<G>(heading_cmd + blend * C[FD_C_LOS_LEAD_ANGLE_RAD] * signv(heading_error));
+        }
+    } else if (gtype == FD_GUIDANCE_PP) {                                    // :146-178
+        const G V = pymax(d.airspeed, G(10));
+        const G turn_radius = (V * V) / (G(9.81) * M<G>::tan(C[FD_C_WP_MAX_BANK_RAD]));
+        G lookahead = C[FD_C_LOOKAHEAD_TIME] * V;
+        const G proximity = C[FD_C_PROXIMITY_SCALE] * turn_radius;
+        if (hd < proximity) lookahead *= G(0.6) + G(0.4) * (hd / proximity);
+        lookahead = clipv(lookahead, C[FD_C_LOOKAHEAD_MIN], C[FD_C_LOOKAHEAD_MAX]);
+        if (hd > G(1)) {
+            const G eff = pymin(lookahead, hd);
+            heading_cmd = M<G>::atan2((e1 / hd) * eff, (e0 / hd) * eff);
+        }
+    }
+    heading_cmd = wrap_pi<G>(heading_cmd);                                   // :185
+
+    G speed_cmd = (wp[FD_WP_SPEED] != wp[FD_WP_SPEED]) ? d.airspeed : wp[FD_WP_SPEED];   // None -> current airspeed
+    G he = M<G>::abs(los - d.heading);                                       // :214-228
+    he = M<G>::abs(wrap_pi<G>(he));
+    const G td = C[FD_C_TURN_THRESHOLD_DIST];
+    if (hd < td && he > C[FD_C_TURN_THRESHOLD_ANGLE_RAD]) {
+        const G reduction = C[FD_C_MAX_SPEED_REDUCTION] * (G(1) - hd / td);
+        speed_cmd = pymax(speed_cmd * (G(1) - reduction), C[FD_C_MIN_SPEED]);
+    }
+    return hsa_agent<G>(cfg, st, C, heading_cmd, speed_cmd, wp[FD_WP_ALTITUDE], x, d, dt);
+}
+
+// controllers/mission_planner.py:128-184 : 3-D acceptance test on the current waypoint
+template <typename G> FD_DEV bool waypoint_reached(const G* C, const G* wp, const G (&x)[FD_NX])
+{
+    const G e0 = wp[FD_WP_NORTH] - x[0], e1 = wp[FD_WP_EAST] - x[1], e2 = (-wp[FD_WP_ALTITUDE]) - x[2];
+    return M<G>::sqrt(e0 * e0 + e1 * e1 + e2 * e2) < C[FD_C_ACCEPTANCE_RADIUS];
+}
+
+// ----- rate-control env pieces ---------------------------------------------------------------------------------
+template <typename G> struct EnvState {
+    G cmd[3], prev_action[4], prev_err[3], sign_changes[3];
+    G settle_timer, is_settled, time, sched[4], ep_return;
+};
+
+// learned_controllers/envs/rewards.py:75-137 (weights :19-25) + SettlingTimeBonus :193-221
+template <typename G>
+FD_DEV G env_reward(EnvState<G>& e, const G (&err)[3], const G (&a)[4], G airspeed, G altitude, G roll, G pitch, G dt)
+{
+    const G tracking_error = (err[0] * err[0] + err[1] * err[1] + err[2] * err[2]) / G(3);
+    const G r_tracking = G(-0.5) * tracking_error;
+    const G d0 = a[0] - e.prev_action[0], d1 = a[1] - e.prev_action[1], d2 = a[2] - e.prev_action[2];
+    const G r_smooth = G(-0.01) * (d0 * d0 + (d1 * d1 + d2 * d2));
+    const G roll_st = M<G>::exp(-M<G>::abs(roll) / deg2rad<G>(45.0));
+    const G pitch_st = M<G>::exp(-M<G>::abs(pitch) / deg2rad<G>(30.0));
+    const G as_st = clipv((airspeed - G(8)) / G(12), G(0), G(1));
+    const G alt_st = clipv((altitude - G(10)) / G(90), G(0), G(1));
+    const G r_stab = G(0.3) * ((roll_st + pitch_st + as_st + alt_st) / G(4));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const G pe = e.prev_err[i];
+        const bool flip = (signv(err[i]) != signv(pe)) && (M<G>::abs(pe) > G(0.01));
+        e.sign_changes[i] = G(0.9) * e.sign_changes[i] + (flip ? G(1) : G(0));
+        e.prev_err[i] = err[i];
+    }
+    const G r_osc = G(-0.1) * (e.sign_changes[0] + (e.sign_changes[1] + e.sign_changes[2]));
+    G r = r_tracking + r_smooth + r_stab + r_osc + G(1);
+
+    bool settled = true;                                                     // rewards.py:197-209
+#pragma unroll
+    for (int i = 0; i < 3; ++i) settled = settled && (M<G>::abs(err[i]) < pymax(M<G>::abs(e.cmd[i]) * G(0.05), G(0.05)));
+    if (settled) {
+        e.settle_timer += dt;
+        if (e.settle_timer >= G(0.2)) { e.is_settled = G(1); r += G(2) * dt; }
+    } else {
+        e.settle_timer = G(0);
+        e.is_settled = G(0);
+    }
+    return r;
+}
+
+// learned_controllers/envs/rate_env.py:374-408
+template <typename G>
+FD_DEV void env_observation(const G (&x)[FD_NX], const EnvState<G>& e, G airspeed, G altitude, float (&o)[FD_OBS_DIM])
+{
+    o[0] = float(x[9]); o[1] = float(x[10]); o[2] = float(x[11]);
+    o[3] = float(e.cmd[0]); o[4] = float(e.cmd[1]); o[5] = float(e.cmd[2]);
+    o[6] = float(e.cmd[0] - x[9]); o[7] = float(e.cmd[1] - x[10]); o[8] = float(e.cmd[2] - x[11]);
+    o[9] = float(airspeed); o[10] = float(altitude);
+    o[11] = float(x[6]); o[12] = float(x[7]); o[13] = float(x[8]);
+    o[14] = float(e.prev_action[0]); o[15] = float(e.prev_action[1]);
+    o[16] = float(e.prev_action[2]); o[17] = float(e.prev_action[3]);
+}
+
+// ----- counter-based generator for throughput-mode resets (Philox-4x32-10) ---------------------------------
+struct Philox {
+    uint32_t c[4], k[2];
+    FD_DEV static void round(uint32_t (&c)[4], const uint32_t (&k)[2])
+    {
+        const uint64_t p0 = uint64_t(0xD2511F53u) * c[0], p1 = uint64_t(0xCD9E8D57u) * c[2];
+        const uint32_t n0 = uint32_t(p1 >> 32) ^ c[1] ^ k[0], n2 = uint32_t(p0 >> 32) ^ c[3] ^ k[1];
+        c[1] = uint32_t(p1); c[3] = uint32_t(p0); c[0] = n0; c[2] = n2;
+    }
+    FD_DEV void block(uint64_t seed, uint32_t a, uint32_t b, uint32_t cc, uint32_t d, uint32_t (&out)[4])
+    {
+        uint32_t ctr[4] = { a, b, cc, d };
+        uint32_t key[2] = { uint32_t(seed), uint32_t(seed >> 32) };
+#pragma unroll
+        for (int i = 0; i < 10; ++i) { round(ctr, key); key[0] += 0x9E3779B9u; key[1] += 0xBB67AE85u; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[i] = ctr[i];
+    }
+};
+FD_DEV float u01(uint32_t r) { return (float(r >> 8) + 0.5f) * (1.0f / 16777216.0f); }   // (0,1)
+
+}  // namespace fdyn

@@ -1,0 +1,684 @@
+// fdyn_kernels.hip -- gfx950 kernels + the C-ABI of include/fdyn.h.
+//
+// Mapping: one lane = one aircraft / env, 256-thread workgroups (4 wave64).  State is structure-of-arrays
+// ([word][N]) so every load/store of a wave is one contiguous 256 B (fp32) / 512 B (fp64) segment.
+// The aircraft "coefficient table" (one FD_NP-word block per aircraft TYPE; the reference has closed-form
+// coefficients, not lookup tables) plus the PID / cascade / waypoint tables are staged in LDS once per
+// workgroup; each lane then pulls its own type's block into registers, so heterogeneous fleets cost nothing
+// extra in the inner loop.  All sub-steps of a launch run out of registers: HBM traffic per launch is one
+// read + one write of the state.  Episode ends are compacted with a wave ballot + mbcnt prefix and ONE
+// atomic per wave into a dense event list (terminal observation, return, length) -- the only inter-lane
+// communication in the path; there is no inter-workgroup communication at all.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include <string.h>
+#include "fdyn_core.hpp"
+#include "../../include/fdyn.h"
+
+using namespace fdyn;
+
+#define FD_BLOCK 256
+#define FD_MAX_TYPES 8
+#define FD_WAVE 64
+
+// ---------------------------------------------------------------------------------------------------------
+// LDS staging helpers
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void stage(T* dst, const T* __restrict__ src, int n)
+{
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+
+__device__ __forceinline__ int lane_type(const uint8_t* __restrict__ type, int64_t i, int n_types)
+{
+    int t = type ? int(type[i]) : 0;
+    return t < n_types ? t : n_types - 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K1: Simplified6DOF.step x n_sub                        (simplified_6dof.py:228-293, simulation_backend.py:95-99)
+// ---------------------------------------------------------------------------------------------------------
+template <typename S, typename T>
+__global__ void __launch_bounds__(FD_BLOCK)
+sixdof_step_kernel(S* __restrict__ xs, const S* __restrict__ us, const uint8_t* __restrict__ type,
+                   const double* __restrict__ params, int n_types, int64_t n, S dt_sub, int n_sub,
+                   S* __restrict__ derived_out)
+{
+    __shared__ double s_params[FD_MAX_TYPES * FD_NP];
+    stage(s_params, params, n_types * FD_NP);
+    __syncthreads();
+    const int64_t i = int64_t(blockIdx.x) * FD_BLOCK + threadIdx.x;
+    if (i >= n) return;
+
+    const double* blk = s_params + lane_type(type, i, n_types) * FD_NP;
+    Params<T> P; P.load(blk);
+    Limits<S> Lm; Lm.load(blk);
+    S x[FD_NX];
+#pragma unroll
+    for (int k = 0; k < FD_NX; ++k) x[k] = xs[k * n + i];
+    Controls<T> C;
+    C.set(P, us[FD_U_ELEVATOR * n + i], us[FD_U_AILERON * n + i], us[FD_U_RUDDER * n + i], us[FD_U_THROTTLE * n + i]);
+
+    for (int s = 0; s < n_sub; ++s) rk4_step<S, T>(P, Lm, C, x, dt_sub);
+
+#pragma unroll
+    for (int k = 0; k < FD_NX; ++k) xs[k * n + i] = x[k];
+    if (derived_out) {
+        const Derived<S> d = derived<S>(x);
+        derived_out[FD_D_AIRSPEED * n + i] = d.airspeed;
+        derived_out[FD_D_ALTITUDE * n + i] = d.altitude;
+        derived_out[FD_D_GROUND_SPEED * n + i] = d.ground_speed;
+        derived_out[FD_D_HEADING * n + i] = d.heading;
+    }
+}
+
+// get_state's derived scalars for a whole fleet (simplified_6dof.py:295-331)
+template <typename S>
+__global__ void __launch_bounds__(FD_BLOCK)
+derived_kernel(const S* __restrict__ xs, int64_t n, S* __restrict__ out)
+{
+    const int64_t i = int64_t(blockIdx.x) * FD_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    S x[FD_NX];
+#pragma unroll
+    for (int k = 0; k < FD_NX; ++k) x[k] = xs[k * n + i];
+    const Derived<S> d = derived<S>(x);
+    out[FD_D_AIRSPEED * n + i] = d.airspeed;
+    out[FD_D_ALTITUDE * n + i] = d.altitude;
+    out[FD_D_GROUND_SPEED * n + i] = d.ground_speed;
+    out[FD_D_HEADING * n + i] = d.heading;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// batched scalar PID (the reference's only native code, cpp/src/pid_controller.cpp:24-60), one lane per loop
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(FD_BLOCK)
+pid_batch_kernel(const float* __restrict__ cfg /*[8] shared or [n][8]*/, int cfg_per_lane,
+                 float* __restrict__ state /*[3][n]*/, const float* __restrict__ setpoint,
+                 const float* __restrict__ measurement, float dt, float* __restrict__ out, int64_t n)
+{
+    const int64_t i = int64_t(blockIdx.x) * FD_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const PidCfg c = load_pid_cfg(cfg + (cfg_per_lane ? i * FD_NPC : 0), 0);
+    PidState s{ state[FD_PS_INTEGRAL * n + i], state[FD_PS_ERR_PREV * n + i], state[FD_PS_DFILT * n + i] };
+    out[i] = pid_compute(c, s, setpoint[i], measurement[i], dt);
+    state[FD_PS_INTEGRAL * n + i] = s.integral;
+    state[FD_PS_ERR_PREV * n + i] = s.err_prev;
+    state[FD_PS_DFILT * n + i] = s.dfilt;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K1+K2: n_steps control steps of the 5-level cascade + one RK4 each
+//        (examples/03_waypoint_square_demo.py:148-209 per aircraft; agents in fdyn_core.hpp)
+// ---------------------------------------------------------------------------------------------------------
+template <typename S, typename T>
+__global__ void __launch_bounds__(FD_BLOCK)
+cascade_step_kernel(S* __restrict__ xs, float* __restrict__ pid_state /*[9*3][n]*/, int32_t* __restrict__ wp_idx,
+                    const uint8_t* __restrict__ type, const double* __restrict__ params, int n_types,
+                    const float* __restrict__ pid_cfg /*[9][8]*/, const double* __restrict__ consts /*[FD_NC]*/,
+                    const double* __restrict__ wps /*[n_wp][4]*/, int n_wp, int64_t n, S dt, int n_steps,
+                    S* __restrict__ surf_out /*[4][n] or null*/, int32_t* __restrict__ reached_total /*[n] or null*/)
+{
+    __shared__ double s_params[FD_MAX_TYPES * FD_NP];
+    __shared__ float s_pid_cfg[FD_NPID * FD_NPC];
+    __shared__ S s_consts[FD_NC];
+    __shared__ S s_wps[FD_MAX_WAYPOINTS * FD_NWP];
+    stage(s_params, params, n_types * FD_NP);
+    stage(s_pid_cfg, pid_cfg, FD_NPID * FD_NPC);
+    for (int k = threadIdx.x; k < FD_NC; k += blockDim.x) s_consts[k] = S(consts[k]);
+    for (int k = threadIdx.x; k < n_wp * FD_NWP; k += blockDim.x) s_wps[k] = S(wps[k]);
+    __syncthreads();
+    const int64_t i = int64_t(blockIdx.x) * FD_BLOCK + threadIdx.x;
+    if (i >= n) return;
+
+    const double* blk = s_params + lane_type(type, i, n_types) * FD_NP;
+    Params<T> P; P.load(blk);
+    Limits<S> Lm; Lm.load(blk);
+    PidCfg cfg[FD_NPID];
+    PidState st[FD_NPID];
+#pragma unroll
+    for (int k = 0; k < FD_NPID; ++k) {
+        cfg[k] = load_pid_cfg(s_pid_cfg, k);
+        st[k] = PidState{ pid_state[(k * FD_NPS + FD_PS_INTEGRAL) * n + i], pid_state[(k * FD_NPS + FD_PS_ERR_PREV) * n + i],
+                          pid_state[(k * FD_NPS + FD_PS_DFILT) * n + i] };
+    }
+    S x[FD_NX];
+#pragma unroll
+    for (int k = 0; k < FD_NX; ++k) x[k] = xs[k * n + i];
+    int32_t idx = wp_idx[i];
+    int32_t reached = 0;
+    const bool restart = int(s_consts[FD_C_ON_COMPLETE]) == 1;
+    Surfaces<S> surf{ S(0), S(0), S(0), S(0) };
+
+    for (int s = 0; s < n_steps; ++s) {
+        if (idx < n_wp && waypoint_reached<S>(s_consts, s_wps + idx * FD_NWP, x)) { idx += 1; reached += 1; }   // mission.update
+        if (idx >= n_wp) { if (restart) idx = 0; else break; }              // COMPLETE: freeze this aircraft
+        const Derived<S> d = derived<S>(x);
+        surf = waypoint_agent<S>(cfg, st, s_consts, s_wps + idx * FD_NWP, x, d, dt);
+        Controls<T> C;
+        C.set(P, surf.elevator, surf.aileron, surf.rudder, surf.throttle);
+        rk4_step<S, T>(P, Lm, C, x, dt);
+    }
+
+#pragma unroll
+    for (int k = 0; k < FD_NX; ++k) xs[k * n + i] = x[k];
+#pragma unroll
+    for (int k = 0; k < FD_NPID; ++k) {
+        pid_state[(k * FD_NPS + FD_PS_INTEGRAL) * n + i] = st[k].integral;
+        pid_state[(k * FD_NPS + FD_PS_ERR_PREV) * n + i] = st[k].err_prev;
+        pid_state[(k * FD_NPS + FD_PS_DFILT) * n + i] = st[k].dfilt;
+    }
+    wp_idx[i] = idx;
+    if (reached_total) reached_total[i] += reached;
+    if (surf_out) {
+        surf_out[FD_U_ELEVATOR * n + i] = surf.elevator; surf_out[FD_U_AILERON * n + i] = surf.aileron;
+        surf_out[FD_U_RUDDER * n + i] = surf.rudder; surf_out[FD_U_THROTTLE * n + i] = surf.throttle;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K3+K4: RateControlEnv.step for a whole vec-env, with done compaction and in-kernel auto-reset
+// ---------------------------------------------------------------------------------------------------------
+template <typename G> struct EnvConsts {
+    G dt, mr0, mr1, mr2, scale;     // separate scalars: an indexed array here ends up in scratch
+    int max_steps, cmd_type, n_sub;
+    // arithmetic select: a ?: chain over struct fields is turned back into an indexed (scratch) load by the compiler
+    __device__ __forceinline__ G max_rate(int ax) const { return mr0 * G(ax == 0) + mr1 * G(ax == 1) + mr2 * G(ax == 2); }
+};
+
+template <typename G>
+__device__ __forceinline__ void env_load(EnvState<G>& e, const G* __restrict__ es, int64_t n, int64_t i)
+{
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        e.cmd[k] = es[(FD_E_CMD_P + k) * n + i];
+        e.prev_err[k] = es[(FD_E_PERR_P + k) * n + i];
+        e.sign_changes[k] = es[(FD_E_SIGN_P + k) * n + i];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { e.prev_action[k] = es[(FD_E_PREV_AIL + k) * n + i]; e.sched[k] = es[(FD_E_SCHED0 + k) * n + i]; }
+    e.settle_timer = es[FD_E_SETTLE_TIMER * n + i]; e.is_settled = es[FD_E_IS_SETTLED * n + i];
+    e.time = es[FD_E_TIME * n + i]; e.ep_return = es[FD_E_EP_RETURN * n + i];
+}
+template <typename G>
+__device__ __forceinline__ void env_store(const EnvState<G>& e, G* __restrict__ es, int64_t n, int64_t i)
+{
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        es[(FD_E_CMD_P + k) * n + i] = e.cmd[k];
+        es[(FD_E_PERR_P + k) * n + i] = e.prev_err[k];
+        es[(FD_E_SIGN_P + k) * n + i] = e.sign_changes[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { es[(FD_E_PREV_AIL + k) * n + i] = e.prev_action[k]; es[(FD_E_SCHED0 + k) * n + i] = e.sched[k]; }
+    es[FD_E_SETTLE_TIMER * n + i] = e.settle_timer; es[FD_E_IS_SETTLED * n + i] = e.is_settled;
+    es[FD_E_TIME * n + i] = e.time; es[FD_E_EP_RETURN * n + i] = e.ep_return;
+}
+
+// one reset record drawn on the device (throughput mode): same distributions as
+// learned_controllers/data/generators.py:47-72,74-125,190-214 and rate_env.py:306, Philox instead of MT19937
+template <typename G>
+__device__ __forceinline__ void device_reset_record(uint64_t seed, uint32_t env, uint32_t episode,
+                                                    const EnvConsts<G>& ec, G (&rec)[FD_NR])
+{
+    Philox ph;
+    uint32_t r0[4], r1[4], r2[4], r3[4];
+    ph.block(seed, env, episode, 0u, 0u, r0);
+    ph.block(seed, env, episode, 0u, 1u, r1);
+    ph.block(seed, env, episode, 0u, 2u, r2);
+    ph.block(seed, env, episode, 0u, 3u, r3);
+    const float d15 = 0.26179938779914943f;     // radians(15)
+    rec[FD_R_AIRSPEED] = G(15.0f + 15.0f * u01(r0[0]));
+    rec[FD_R_ALTITUDE] = G(50.0f + 150.0f * u01(r0[1]));
+    rec[FD_R_ROLL] = G(-d15 + 2.0f * d15 * u01(r0[2]));
+    rec[FD_R_PITCH] = G(-d15 + 2.0f * d15 * u01(r0[3]));
+    rec[FD_R_YAW] = G(6.283185307179586f * u01(r1[0]));
+    rec[FD_R_P] = G(-0.1f + 0.2f * u01(r1[1]));
+    rec[FD_R_Q] = G(-0.1f + 0.2f * u01(r1[2]));
+    rec[FD_R_R] = G(-0.1f + 0.2f * u01(r1[3]));
+    rec[FD_R_CMD0] = rec[FD_R_CMD1] = rec[FD_R_CMD2] = rec[FD_R_CMD3] = G(0);
+    if (ec.cmd_type == FD_CMD_RANDOM_WALK) return;
+    const bool sine = ec.cmd_type == FD_CMD_SINE;
+    int k = sine ? 1 + int(u01(r2[0]) * 2.0f) : 1 + int(u01(r2[0]) * 3.0f);          // number of active axes
+    k = k > 3 ? 3 : k;
+    // Which axes are active: a random permutation (first, second, third) of the three axes, first k of it active.
+    // Everything below is straight-line scalar selects with STATIC array indices: a run-time index into a private
+    // array (or a ?: chain over array elements, which the compiler folds back into one) is mis-compiled / spilled.
+    const int perm = int(u01(r2[1]) * 6.0f) % 6;
+    const int first = perm >> 1;
+    const int o1 = first == 2 ? 0 : first + 1, o2 = first == 0 ? 2 : first - 1;
+    const int second = (perm & 1) ? o2 : o1;
+    const float m0 = u01(r3[0]), m1 = u01(r3[1]), m2 = u01(r3[2]);
+    const G mrs[3] = { ec.mr0, ec.mr1, ec.mr2 };
+    G vals[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {                                  // a is a compile-time constant after unrolling
+        const int pos = (a == first) ? 0 : ((a == second) ? 1 : 2);
+        const float um = pos == 0 ? m0 : (pos == 1 ? m1 : m2);
+        float mag = (0.3f + 0.7f * um) * float(ec.scale);
+        if (sine) mag *= 0.5f;
+        const float sgn = (!sine && ((r2[2] >> pos) & 1u)) ? -1.0f : 1.0f;
+        vals[a] = (pos < k) ? G(sgn * mag) * mrs[a] : G(0);
+    }
+    rec[FD_R_CMD0] = vals[0]; rec[FD_R_CMD1] = vals[1]; rec[FD_R_CMD2] = vals[2];
+    if (sine) rec[FD_R_CMD3] = G(0.1f + 1.9f * u01(r2[3]));
+}
+
+// RateControlEnv.reset body (rate_env.py:170-204) from one record
+template <typename G>
+__device__ __forceinline__ void env_apply_reset(const G (&rec)[FD_NR], int cmd_type, G (&x)[FD_NX], EnvState<G>& e)
+{
+#pragma unroll
+    for (int k = 0; k < FD_NX; ++k) x[k] = G(0);
+    x[2] = -rec[FD_R_ALTITUDE]; x[3] = rec[FD_R_AIRSPEED];
+    x[6] = rec[FD_R_ROLL]; x[7] = rec[FD_R_PITCH]; x[8] = rec[FD_R_YAW];
+    x[9] = rec[FD_R_P]; x[10] = rec[FD_R_Q]; x[11] = rec[FD_R_R];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { e.cmd[k] = G(0); e.prev_err[k] = G(0); e.sign_changes[k] = G(0); e.prev_action[k] = G(0); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e.sched[k] = G(0);
+    e.prev_action[3] = G(0.5);                                                   // rate_env.py:193
+    if (cmd_type == FD_CMD_STEP) {
+        e.cmd[0] = rec[FD_R_CMD0]; e.cmd[1] = rec[FD_R_CMD1]; e.cmd[2] = rec[FD_R_CMD2];
+    } else if (cmd_type == FD_CMD_RAMP || cmd_type == FD_CMD_SINE) {
+        e.sched[0] = rec[FD_R_CMD0]; e.sched[1] = rec[FD_R_CMD1]; e.sched[2] = rec[FD_R_CMD2]; e.sched[3] = rec[FD_R_CMD3];
+    }
+    e.settle_timer = G(0); e.is_settled = G(0); e.time = G(0); e.ep_return = G(0);
+}
+
+template <typename G>
+__device__ __forceinline__ void load_env_consts(const double* __restrict__ EC, EnvConsts<G>& ec)
+{
+    ec.dt = G(EC[FD_EC_DT]);
+    ec.max_steps = int(EC[FD_EC_MAX_STEPS]);
+    ec.cmd_type = int(EC[FD_EC_CMD_TYPE]);
+    ec.scale = G(EC[FD_EC_DIFFICULTY_SCALE]);
+    ec.mr0 = G(EC[FD_EC_MAX_RATE_P]); ec.mr1 = G(EC[FD_EC_MAX_RATE_Q]); ec.mr2 = G(EC[FD_EC_MAX_RATE_R]);
+    const double r = EC[FD_EC_DT] / EC[FD_EC_DT_PHYSICS];                       // simulation_backend.py:95
+    const long ns = long(r);
+    ec.n_sub = ns < 1 ? 1 : int(ns);
+}
+
+template <typename G>
+__device__ __forceinline__ void fetch_reset_record(const double* __restrict__ pool, int pool_depth, uint64_t seed,
+                                                   int64_t i, int32_t episode, const EnvConsts<G>& ec, G (&rec)[FD_NR])
+{
+    if (pool) {
+        const double* r = pool + (i * pool_depth + (episode % pool_depth)) * FD_NR;
+#pragma unroll
+        for (int k = 0; k < FD_NR; ++k) rec[k] = G(r[k]);
+    } else {
+        device_reset_record<G>(seed, uint32_t(i), uint32_t(episode), ec, rec);
+    }
+}
+
+// coalesced write-out of a wave's 64 x 18 observation tile through LDS (row stride 19 words: conflict-free)
+__device__ __forceinline__ void store_obs_tile(float* tile /*[64*19]*/, const float (&o)[FD_OBS_DIM], int lane,
+                                               float* __restrict__ obs_out, int64_t wave_first, int64_t n)
+{
+#pragma unroll
+    for (int k = 0; k < FD_OBS_DIM; ++k) tile[lane * (FD_OBS_DIM + 1) + k] = o[k];
+    __builtin_amdgcn_wave_barrier();
+    const int64_t valid = (n - wave_first) < FD_WAVE ? (n - wave_first) : FD_WAVE;
+    float* dst = obs_out + wave_first * FD_OBS_DIM;
+#pragma unroll
+    for (int k = 0; k < FD_OBS_DIM; ++k) {
+        const int flat = k * FD_WAVE + lane;
+        const int row = flat / FD_OBS_DIM, col = flat - row * FD_OBS_DIM;
+        if (row < valid) dst[flat] = tile[row * (FD_OBS_DIM + 1) + col];
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <typename S>
+__global__ void __launch_bounds__(FD_BLOCK)
+rate_env_reset_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict__ eis, float* __restrict__ pid_state,
+                      const uint8_t* __restrict__ mask, const double* __restrict__ EC, const double* __restrict__ pool,
+                      int pool_depth, uint64_t seed, float* __restrict__ obs_out, int64_t n)
+{
+    __shared__ float s_tile[FD_BLOCK / FD_WAVE][FD_WAVE * (FD_OBS_DIM + 1)];
+    const int64_t i = int64_t(blockIdx.x) * FD_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & (FD_WAVE - 1), wave = threadIdx.x / FD_WAVE;
+    const bool active = i < n;
+    EnvConsts<S> ec;
+    load_env_consts<S>(EC, ec);
+    S x[FD_NX];
+    EnvState<S> e;
+    float o[FD_OBS_DIM];
+#pragma unroll
+    for (int k = 0; k < FD_OBS_DIM; ++k) o[k] = 0.0f;
+    if (active) {
+        const bool doit = mask ? mask[i] != 0 : true;
+        if (doit) {
+            const int32_t episode = eis[FD_EI_EPISODE * n + i];
+            S rec[FD_NR];
+            fetch_reset_record<S>(pool, pool_depth, seed, i, episode, ec, rec);
+            env_apply_reset<S>(rec, ec.cmd_type, x, e);
+#pragma unroll
+            for (int k = 0; k < FD_NX; ++k) xs[k * n + i] = x[k];
+            env_store<S>(e, es, n, i);
+            eis[FD_EI_STEP * n + i] = 0;
+            eis[FD_EI_EPISODE * n + i] = episode + 1;
+            if (pid_state) for (int k = 0; k < 3 * FD_NPS; ++k) pid_state[k * n + i] = 0.0f;
+        } else {
+#pragma unroll
+            for (int k = 0; k < FD_NX; ++k) x[k] = xs[k * n + i];
+            env_load<S>(e, es, n, i);
+        }
+        S airspeed, altitude;
+        airspeed_altitude<S>(x, airspeed, altitude);
+        env_observation<S>(x, e, airspeed, altitude, o);
+    }
+    store_obs_tile(s_tile[wave], o, lane, obs_out, i - lane, n);
+}
+
+template <typename S, typename T>
+__global__ void __launch_bounds__(FD_BLOCK)
+rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict__ eis,
+                     const uint8_t* __restrict__ type, const double* __restrict__ params, int n_types,
+                     const double* __restrict__ EC,
+                     const float* __restrict__ actions /*[n][4] or null => in-kernel rate PID*/,
+                     float* __restrict__ pid_state /*[3*3][n], PID mode*/, const float* __restrict__ pid_cfg /*[9][8]*/,
+                     const double* __restrict__ casc_consts /*[FD_NC], PID mode*/, float* __restrict__ actions_out,
+                     const S* __restrict__ rw_delta /*[3][n] or null*/,
+                     const double* __restrict__ pool, int pool_depth, uint64_t seed, int auto_reset,
+                     float* __restrict__ obs_out /*[n][18]*/, float* __restrict__ reward_f32, S* __restrict__ reward_full,
+                     uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
+                     int32_t* __restrict__ ev_count, int32_t* __restrict__ ev_int, float* __restrict__ ev_flt, int ev_cap,
+                     int64_t n)
+{
+    __shared__ double s_params[FD_MAX_TYPES * FD_NP];
+    __shared__ float s_tile[FD_BLOCK / FD_WAVE][FD_WAVE * (FD_OBS_DIM + 1)];
+    __shared__ float s_pid_cfg[3 * FD_NPC];
+    __shared__ S s_consts[FD_NC];
+    stage(s_params, params, n_types * FD_NP);
+    const bool pid_mode = actions == nullptr;
+    if (pid_mode) {
+        stage(s_pid_cfg, pid_cfg, 3 * FD_NPC);
+        for (int k = threadIdx.x; k < FD_NC; k += blockDim.x) s_consts[k] = S(casc_consts[k]);
+    }
+    __syncthreads();
+
+    const int64_t i = int64_t(blockIdx.x) * FD_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & (FD_WAVE - 1), wave = threadIdx.x / FD_WAVE;
+    const bool active = i < n;
+    EnvConsts<S> ec;
+    load_env_consts<S>(EC, ec);
+
+    float o[FD_OBS_DIM];
+#pragma unroll
+    for (int k = 0; k < FD_OBS_DIM; ++k) o[k] = 0.0f;
+    bool done = false, term = false;
+    S x[FD_NX];
+    EnvState<S> e;
+    S reward = S(0);
+    int32_t step = 0, episode = 0;
+
+    if (active) {
+        const double* blk = s_params + lane_type(type, i, n_types) * FD_NP;
+        Params<T> P; P.load(blk);
+        Limits<S> Lm; Lm.load(blk);
+#pragma unroll
+        for (int k = 0; k < FD_NX; ++k) x[k] = xs[k * n + i];
+        env_load<S>(e, es, n, i);
+        step = eis[FD_EI_STEP * n + i];
+        episode = eis[FD_EI_EPISODE * n + i];
+
+        // ---- action: from the policy ([n][4] f32, one 16-B load per lane) or the fused rate PID -------------
+        float a_in[4];
+        if (!pid_mode) {
+            const float4 av = reinterpret_cast<const float4*>(actions)[i];
+            a_in[0] = av.x; a_in[1] = av.y; a_in[2] = av.z; a_in[3] = av.w;
+        } else {                                         // learned_controllers/utils/pid_demonstrations.py:47-77
+            PidCfg cfg[3]; PidState st[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                cfg[k] = load_pid_cfg(s_pid_cfg, k);
+                st[k] = PidState{ pid_state[(k * FD_NPS + 0) * n + i], pid_state[(k * FD_NPS + 1) * n + i], pid_state[(k * FD_NPS + 2) * n + i] };
+            }
+            const Surfaces<S> sf = rate_agent<S>(cfg, st, s_consts, e.cmd[0], e.cmd[1], e.cmd[2], S(0.6), x, ec.dt);
+            a_in[0] = float(sf.aileron); a_in[1] = float(sf.elevator); a_in[2] = float(sf.rudder); a_in[3] = float(sf.throttle);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                pid_state[(k * FD_NPS + 0) * n + i] = st[k].integral; pid_state[(k * FD_NPS + 1) * n + i] = st[k].err_prev;
+                pid_state[(k * FD_NPS + 2) * n + i] = st[k].dfilt;
+            }
+        }
+        if (actions_out) reinterpret_cast<float4*>(actions_out)[i] = make_float4(a_in[0], a_in[1], a_in[2], a_in[3]);
+        S a[4];                                                                   // rate_env.py:225
+        a[0] = clipv(S(a_in[0]), S(-1), S(1)); a[1] = clipv(S(a_in[1]), S(-1), S(1));
+        a[2] = clipv(S(a_in[2]), S(-1), S(1)); a[3] = clipv(S(a_in[3]), S(0), S(1));
+
+        // ---- sim.set_controls + sim.step(dt): n_sub RK4 sub-steps in registers (rate_env.py:228-237) --------
+        Controls<T> C;
+        C.set(P, a[1], a[0], a[2], a[3]);                                         // action = [ail, elev, rud, thr]
+        const S dt_sub = ec.dt / S(ec.n_sub);
+        for (int s = 0; s < ec.n_sub; ++s) rk4_step<S, T>(P, Lm, C, x, dt_sub);
+        e.time += ec.dt;                                                          // :241-242
+        step += 1;
+
+        // ---- _update_command (rate_env.py:342-372) ------------------------------------------------------------
+        if (ec.cmd_type == FD_CMD_RAMP) {
+            const S t = e.time;
+            if (t < S(3)) {
+                const S alpha = t / S(3);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) e.cmd[k] = (S(1) - alpha) * S(0) + alpha * e.sched[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) e.cmd[k] = e.sched[k];
+            }
+        } else if (ec.cmd_type == FD_CMD_RANDOM_WALK) {
+            S delta[3];
+            if (rw_delta) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) delta[k] = rw_delta[k * n + i];
+            } else {                                                              // generators.py:147-164 on device
+                Philox ph; uint32_t r[4];
+                ph.block(seed, uint32_t(i), uint32_t(episode), uint32_t(step), 7u, r);
+                const float m0 = sqrtf(-2.0f * logf(u01(r[0]))), m1 = sqrtf(-2.0f * logf(u01(r[2])));
+                const float n0 = m0 * cosf(6.283185307f * u01(r[1])), n1 = m0 * sinf(6.283185307f * u01(r[1]));
+                const float n2 = m1 * cosf(6.283185307f * u01(r[3]));
+                const S sd = S(0.1) * M<S>::sqrt(ec.dt) * ec.scale;
+                delta[0] = S(n0) * sd * ec.mr0; delta[1] = S(n1) * sd * ec.mr1; delta[2] = S(n2) * sd * ec.mr2;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) e.cmd[k] = clipv(e.cmd[k] + delta[k], -ec.max_rate(k), ec.max_rate(k));
+        } else if (ec.cmd_type == FD_CMD_SINE) {
+            const S sn = M<S>::sin(S(2.0 * FD_PI) * e.sched[3] * e.time);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) e.cmd[k] = e.sched[k] * sn;
+        }
+
+        // ---- reward, termination (rate_env.py:247-294,437-460) -------------------------------------------------
+        S airspeed, altitude;
+        airspeed_altitude<S>(x, airspeed, altitude);
+        const S err[3] = { e.cmd[0] - x[9], e.cmd[1] - x[10], e.cmd[2] - x[11] };
+        reward = env_reward<S>(e, err, a, airspeed, altitude, x[6], x[7], ec.dt);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e.prev_action[k] = a[k];                      // :282
+        term = (altitude < S(5)) || (M<S>::abs(x[6]) > deg2rad<S>(120.0)) || (M<S>::abs(x[7]) > deg2rad<S>(80.0)) ||
+               (airspeed < S(8));
+        const bool trunc = step >= ec.max_steps;
+        if (term && !trunc) reward += S(-100);                                    // :289-292
+        e.ep_return += reward;
+        done = term || trunc;
+        env_observation<S>(x, e, airspeed, altitude, o);
+        if (reward_f32) reward_f32[i] = float(reward);
+        if (reward_full) reward_full[i] = reward;
+        terminated[i] = term ? 1 : 0;
+        truncated[i] = trunc ? 1 : 0;
+    }
+
+    // ---- K4: episode-done compaction -- wave ballot + mbcnt prefix, one atomic per wave ---------------------
+    const unsigned long long done_mask = __ballot(done);
+    if (done_mask != 0ull && ev_count != nullptr) {
+        const int n_done = __popcll(done_mask);
+        const int prefix = __builtin_amdgcn_mbcnt_hi(uint32_t(done_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(done_mask), 0u));
+        const int leader = __ffsll((long long)done_mask) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(ev_count, n_done);
+        base = __shfl(base, leader, FD_WAVE);
+        const int slot = base + prefix;
+        if (done && slot < ev_cap) {
+            ev_int[slot * FD_EV_NI + FD_EV_ENV] = int32_t(i);
+            ev_int[slot * FD_EV_NI + FD_EV_LENGTH] = step;
+            ev_int[slot * FD_EV_NI + FD_EV_TERMINATED] = term ? 1 : 0;
+            ev_flt[slot * FD_EV_NF] = float(e.ep_return);
+#pragma unroll
+            for (int k = 0; k < FD_OBS_DIM; ++k) ev_flt[slot * FD_EV_NF + 1 + k] = o[k];
+        }
+    }
+
+    // ---- in-kernel auto-reset (vec-env semantics: the returned observation is the post-reset one) -----------
+    if (active) {
+        if (done && auto_reset) {
+            S rec[FD_NR];
+            fetch_reset_record<S>(pool, pool_depth, seed, i, episode, ec, rec);
+            env_apply_reset<S>(rec, ec.cmd_type, x, e);
+            step = 0;
+            episode += 1;
+            S airspeed, altitude;
+            airspeed_altitude<S>(x, airspeed, altitude);
+            env_observation<S>(x, e, airspeed, altitude, o);
+            if (pid_mode) for (int k = 0; k < 3 * FD_NPS; ++k) pid_state[k * n + i] = 0.0f;   // pid_agent.reset()
+        }
+#pragma unroll
+        for (int k = 0; k < FD_NX; ++k) xs[k * n + i] = x[k];
+        env_store<S>(e, es, n, i);
+        eis[FD_EI_STEP * n + i] = step;
+        eis[FD_EI_EPISODE * n + i] = episode;
+    }
+    store_obs_tile(s_tile[wave], o, lane, obs_out, i - lane, n);
+}
+
+// =========================================================================================================
+// C-ABI (include/fdyn.h)
+// =========================================================================================================
+static inline unsigned grid_for(int64_t n) { return unsigned((n + FD_BLOCK - 1) / FD_BLOCK); }
+static inline int launch_status() { return int(hipGetLastError()); }
+
+#define FD_CHECK_COMMON(n, n_types)                                       \
+    if ((n) < 0 || (n) > (int64_t(1) << 31) - FD_BLOCK) return FDYN_ERR_BAD_SIZE;   \
+    if ((n_types) < 1 || (n_types) > FD_MAX_TYPES) return FDYN_ERR_BAD_TYPES;       \
+    if ((n) == 0) return FDYN_OK;
+
+extern "C" {
+
+int fdyn_abi_version(void) { return FDYN_ABI_VERSION; }
+
+int fdyn_num_substeps(double dt, double dt_physics)
+{   // simulation/simulation_backend.py:95  max(1, int(dt / dt_physics))
+    const double r = dt / dt_physics;
+    const long n = long(r);
+    return n < 1 ? 1 : int(n);
+}
+
+int fdyn_device_info(int* cu_count, int* wave_size, char* arch, int arch_len)
+{
+    hipDeviceProp_t p;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return int(e);
+    e = hipGetDeviceProperties(&p, dev);
+    if (e != hipSuccess) return int(e);
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (wave_size) *wave_size = p.warpSize;
+    if (arch && arch_len > 0) { strncpy(arch, p.gcnArchName, arch_len - 1); arch[arch_len - 1] = 0; }
+    return FDYN_OK;
+}
+
+#define FD_DEFINE_SIXDOF(NAME, S, T)                                                                         \
+    int NAME(S* x, const S* u, const uint8_t* type, const double* params, int n_types, int64_t n, double dt, \
+             int n_sub, S* derived_out, void* stream)                                                        \
+    {                                                                                                        \
+        FD_CHECK_COMMON(n, n_types)                                                                          \
+        if (n_sub < 1) return FDYN_ERR_BAD_SIZE;                                                             \
+        const double dt_sub = dt / n_sub;                                                                    \
+        /* simplified_6dof.py:241-245: dt <= min_timestep or > max_timestep raises ValueError (defaults) */ \
+        if (!(dt_sub > 1e-6) || dt_sub > 1.0) return FDYN_ERR_BAD_DT;                                        \
+        hipLaunchKernelGGL((sixdof_step_kernel<S, T>), dim3(grid_for(n)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
+                           x, u, type, params, n_types, n, S(dt_sub), n_sub, derived_out);                   \
+        return launch_status();                                                                              \
+    }
+FD_DEFINE_SIXDOF(fdyn_sixdof_step_f64, double, double)
+FD_DEFINE_SIXDOF(fdyn_sixdof_step_mixed, double, float)
+FD_DEFINE_SIXDOF(fdyn_sixdof_step_f32, float, float)
+
+int fdyn_derived_f64(const double* x, int64_t n, double* out, void* stream)
+{
+    FD_CHECK_COMMON(n, 1)
+    hipLaunchKernelGGL((derived_kernel<double>), dim3(grid_for(n)), dim3(FD_BLOCK), 0, (hipStream_t)stream, x, n, out);
+    return launch_status();
+}
+int fdyn_derived_f32(const float* x, int64_t n, float* out, void* stream)
+{
+    FD_CHECK_COMMON(n, 1)
+    hipLaunchKernelGGL((derived_kernel<float>), dim3(grid_for(n)), dim3(FD_BLOCK), 0, (hipStream_t)stream, x, n, out);
+    return launch_status();
+}
+
+int fdyn_pid_compute_batch(const float* cfg, int cfg_per_lane, float* state, const float* setpoint,
+                           const float* measurement, float dt, float* out, int64_t n, void* stream)
+{
+    FD_CHECK_COMMON(n, 1)
+    hipLaunchKernelGGL(pid_batch_kernel, dim3(grid_for(n)), dim3(FD_BLOCK), 0, (hipStream_t)stream, cfg, cfg_per_lane,
+                       state, setpoint, measurement, dt, out, n);
+    return launch_status();
+}
+
+#define FD_DEFINE_CASCADE(NAME, S, T)                                                                        \
+    int NAME(S* x, float* pid_state, int32_t* wp_idx, const uint8_t* type, const double* params, int n_types, \
+             const float* pid_cfg, const double* consts, const double* wps, int n_wp, int64_t n, double dt,  \
+             int n_steps, S* surf_out, int32_t* reached_total, void* stream)                                 \
+    {                                                                                                        \
+        FD_CHECK_COMMON(n, n_types)                                                                          \
+        if (n_wp < 1 || n_wp > FD_MAX_WAYPOINTS || n_steps < 0) return FDYN_ERR_BAD_SIZE;                    \
+        if (!(dt > 1e-6) || dt > 1.0) return FDYN_ERR_BAD_DT;                                                \
+        hipLaunchKernelGGL((cascade_step_kernel<S, T>), dim3(grid_for(n)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
+                           x, pid_state, wp_idx, type, params, n_types, pid_cfg, consts, wps, n_wp, n, S(dt), \
+                           n_steps, surf_out, reached_total);                                                \
+        return launch_status();                                                                              \
+    }
+FD_DEFINE_CASCADE(fdyn_cascade_step_f64, double, double)
+FD_DEFINE_CASCADE(fdyn_cascade_step_mixed, double, float)
+FD_DEFINE_CASCADE(fdyn_cascade_step_f32, float, float)
+
+#define FD_DEFINE_ENV(SUFFIX, S, T)                                                                          \
+    int fdyn_rate_env_reset_##SUFFIX(S* x, S* e, int32_t* ei, float* pid_state, const uint8_t* mask,         \
+                                     const double* env_consts, const double* pool, int pool_depth,           \
+                                     uint64_t seed, float* obs_out, int64_t n, void* stream)                 \
+    {                                                                                                        \
+        FD_CHECK_COMMON(n, 1)                                                                                \
+        if (pool && pool_depth < 1) return FDYN_ERR_BAD_SIZE;                                                \
+        hipLaunchKernelGGL((rate_env_reset_kernel<S>), dim3(grid_for(n)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
+                           x, e, ei, pid_state, mask, env_consts, pool, pool_depth, seed, obs_out, n);       \
+        return launch_status();                                                                              \
+    }                                                                                                        \
+    int fdyn_rate_env_step_##SUFFIX(S* x, S* e, int32_t* ei, const uint8_t* type, const double* params,      \
+                                    int n_types, const double* env_consts, const float* actions,             \
+                                    float* pid_state, const float* pid_cfg, const double* casc_consts,       \
+                                    float* actions_out, const S* rw_delta, const double* pool, int pool_depth, \
+                                    uint64_t seed, int auto_reset, float* obs_out, float* reward_f32,        \
+                                    S* reward_full, uint8_t* terminated, uint8_t* truncated,                 \
+                                    int32_t* ev_count, int32_t* ev_int, float* ev_flt, int ev_cap,           \
+                                    int64_t n, void* stream)                                                 \
+    {                                                                                                        \
+        FD_CHECK_COMMON(n, n_types)                                                                          \
+        if (pool && pool_depth < 1) return FDYN_ERR_BAD_SIZE;                                                \
+        if (!actions && !(pid_state && pid_cfg && casc_consts)) return FDYN_ERR_NULL;                        \
+        if (!obs_out || !terminated || !truncated || !env_consts) return FDYN_ERR_NULL;                      \
+        if (ev_count && (!ev_int || !ev_flt || ev_cap < 0)) return FDYN_ERR_NULL;                            \
+        hipLaunchKernelGGL((rate_env_step_kernel<S, T>), dim3(grid_for(n)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
+                           x, e, ei, type, params, n_types, env_consts, actions, pid_state, pid_cfg,         \
+                           casc_consts, actions_out, rw_delta, pool, pool_depth, seed, auto_reset, obs_out,  \
+                           reward_f32, reward_full, terminated, truncated, ev_count, ev_int, ev_flt, ev_cap, n); \
+        return launch_status();                                                                              \
+    }
+FD_DEFINE_ENV(f64, double, double)
+FD_DEFINE_ENV(mixed, double, float)
+FD_DEFINE_ENV(f32, float, float)
+
+}  // extern "C"

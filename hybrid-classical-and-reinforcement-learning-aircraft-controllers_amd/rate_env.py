@@ -1,0 +1,161 @@
+"""Device-resident rate-control environments.
+
+`GpuRateVecEnv` is N `RateControlEnv`s (learned_controllers/envs/rate_env.py:17-470) stepped by ONE fused HIP launch
+per vec-env step: action clip -> 20 RK4 sub-steps -> command update -> reward (+ settling bonus, crash penalty) ->
+termination -> observation -> episode-end compaction -> in-kernel auto-reset.  It presents the vec-env surface the
+reference's trainer drives (`num_envs`, `reset()`, `step(actions)`, `step_async/step_wait`, `close`, `seed`,
+`get_attr/set_attr/env_method`; learned_controllers/utils/training_utils.py:49-69) but hands back device tensors, so
+a policy on the same GPU never crosses PCIe.  `numpy_io=True` returns NumPy like the reference's vec-env does.
+
+Episode sampling: `parity` mode replays NumPy MT19937 streams pre-sampled on the host in the reference's exact call
+order (samplers.presample_reset_pool; identical seeds => identical episodes); `device` mode draws in-kernel (Philox).
+"""
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib, layout as L
+from .config import cascade_consts, pid_table
+from .params import param_table
+from .samplers import COMMAND_TYPE, EpisodeStreams, env_consts, presample_reset_pool
+
+
+class GpuRateVecEnv:
+    def __init__(self, num_envs: int, difficulty: str = "medium", episode_length: float = 10.0, dt: float = 0.02,
+                 command_type: str = "step", seed: Optional[int] = None, precision: str = "mixed",
+                 sampling: str = "device", pool_depth: int = 8, types: Sequence = ("rc_plane",),
+                 type_index: Optional[np.ndarray] = None, event_capacity: Optional[int] = None,
+                 numpy_io: bool = False, device=None):
+        self.lib = _lib.load()
+        self.device = device or _lib.require_gpu()
+        self.num_envs = self.n = int(num_envs)
+        self.precision, self.dtype = precision, _lib.state_dtype(precision)
+        self.difficulty, self.episode_length, self.dt, self.command_type = difficulty, episode_length, dt, command_type
+        self.seed_value = 0 if seed is None else int(seed)
+        self.numpy_io = numpy_io
+        dev, n = self.device, self.n
+        self.env_consts_host = env_consts(difficulty, episode_length, dt, command_type)
+        self.env_consts = torch.as_tensor(self.env_consts_host, device=dev)
+        self.params = torch.as_tensor(param_table(types), device=dev).contiguous()
+        self.n_types = self.params.shape[0]
+        self.type_index = None if type_index is None else torch.as_tensor(np.asarray(type_index, np.uint8), device=dev)
+        self.x = torch.zeros((L.FD_NX, n), dtype=self.dtype, device=dev)
+        self.e = torch.zeros((L.FD_NE, n), dtype=self.dtype, device=dev)
+        self.ei = torch.zeros((L.FD_NEI, n), dtype=torch.int32, device=dev)
+        self.obs = torch.zeros((n, L.FD_OBS_DIM), dtype=torch.float32, device=dev)
+        self.rewards = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.rewards_full = torch.zeros(n, dtype=self.dtype, device=dev)
+        self.terminated = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self.truncated = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self.actions_taken = torch.zeros((n, L.FD_ACT_DIM), dtype=torch.float32, device=dev)
+        # compacted episode-end records
+        self.ev_cap = int(event_capacity if event_capacity is not None else n)
+        self.ev_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.ev_int = torch.zeros((max(self.ev_cap, 1), L.FD_EV_NI), dtype=torch.int32, device=dev)
+        self.ev_flt = torch.zeros((max(self.ev_cap, 1), L.FD_EV_NF), dtype=torch.float32, device=dev)
+        # fused PID demonstrator (learned_controllers/utils/pid_demonstrations.py:41-77)
+        self.pid_state = torch.zeros((3 * L.FD_NPS, n), dtype=torch.float32, device=dev)
+        self.pid_cfg = torch.as_tensor(pid_table(), device=dev)
+        self.casc_consts = torch.as_tensor(cascade_consts(), device=dev)
+        # episode sampling
+        self.sampling = sampling
+        self.pool, self.pool_depth, self._streams = None, 0, None
+        if sampling == "parity":
+            seeds = [None if seed is None else seed + i for i in range(n)]       # make_env: rng_seed = seed + rank
+            self.pool_depth = int(pool_depth)
+            self.pool = torch.as_tensor(presample_reset_pool(seeds, pool_depth, difficulty, command_type), device=dev)
+            if command_type == "random":                                          # per-step random-walk deltas
+                self._streams = [EpisodeStreams(difficulty, command_type, s) for s in seeds]
+        elif sampling != "device":
+            raise ValueError("sampling must be 'parity' or 'device'")
+        self._reset_fn = getattr(self.lib, f"fdyn_rate_env_reset_{precision}")
+        self._step_fn = getattr(self.lib, f"fdyn_rate_env_step_{precision}")
+        self._pending = None
+
+    # ---- vec-env surface ------------------------------------------------------------------------------------
+    def reset(self, mask: Optional[torch.Tensor] = None):
+        m = None if mask is None else mask.to(torch.uint8).contiguous()
+        rc = self._reset_fn(_lib.ptr(self.x), _lib.ptr(self.e), _lib.ptr(self.ei), _lib.ptr(self.pid_state),
+                            _lib.ptr(m), _lib.ptr(self.env_consts), _lib.ptr(self.pool), self.pool_depth,
+                            self.seed_value, _lib.ptr(self.obs), self.n, _lib.current_stream())
+        _lib.check(rc, "RateControlEnv.reset")
+        return self._out(self.obs)
+
+    def step_device(self, actions: Optional[torch.Tensor], auto_reset: bool = True, rw_delta=None):
+        """One fused launch.  `actions` [N,4] fp32 on the device, or None => the fused rate-PID demonstrator."""
+        if actions is not None:
+            actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
+            assert actions.shape == (self.n, L.FD_ACT_DIM)
+        self.ev_count.zero_()
+        rc = self._step_fn(_lib.ptr(self.x), _lib.ptr(self.e), _lib.ptr(self.ei), _lib.ptr(self.type_index),
+                           _lib.ptr(self.params), self.n_types, _lib.ptr(self.env_consts), _lib.ptr(actions),
+                           _lib.ptr(self.pid_state), _lib.ptr(self.pid_cfg), _lib.ptr(self.casc_consts),
+                           _lib.ptr(self.actions_taken), _lib.ptr(rw_delta), _lib.ptr(self.pool), self.pool_depth,
+                           self.seed_value, int(auto_reset), _lib.ptr(self.obs), _lib.ptr(self.rewards),
+                           _lib.ptr(self.rewards_full), _lib.ptr(self.terminated), _lib.ptr(self.truncated),
+                           _lib.ptr(self.ev_count), _lib.ptr(self.ev_int), _lib.ptr(self.ev_flt), self.ev_cap,
+                           self.n, _lib.current_stream())
+        _lib.check(rc, "RateControlEnv.step")
+        return self.obs, self.rewards, self.terminated, self.truncated
+
+    def step(self, actions, auto_reset: bool = True):
+        if isinstance(actions, np.ndarray):
+            actions = torch.as_tensor(actions, dtype=torch.float32, device=self.device)
+        rw = None
+        if self._streams is not None:                                # parity-mode random-walk deltas for THIS step
+            d = np.stack([s.random_walk_delta(self.dt) for s in self._streams], axis=1)
+            rw = torch.as_tensor(np.ascontiguousarray(d), device=self.device).to(self.dtype)
+        obs, rew, term, trunc = self.step_device(actions, auto_reset, rw)
+        dones = (term | trunc).bool()
+        if self.numpy_io:
+            return obs.cpu().numpy(), rew.cpu().numpy(), dones.cpu().numpy(), self.episode_infos()
+        return obs, rew, dones, None
+
+    def step_async(self, actions):
+        self._pending = actions
+
+    def step_wait(self):
+        a, self._pending = self._pending, None
+        return self.step(a)
+
+    def episode_events(self):
+        """Compacted records of the episodes that ended in the last step (one small D2H copy of the count)."""
+        k = min(int(self.ev_count.item()), self.ev_cap)
+        return self.ev_int[:k], self.ev_flt[:k]
+
+    def episode_infos(self):
+        """Per-env info dicts in the vec-env convention: `episode` = {r, l}, `terminal_observation`."""
+        infos = [{} for _ in range(self.n)]
+        ints, flts = self.episode_events()
+        ints, flts = ints.cpu().numpy(), flts.cpu().numpy()
+        for (env, length, term), f in zip(ints, flts):
+            infos[env] = {"episode": {"r": float(f[0]), "l": int(length)}, "terminal_observation": f[1:].copy(),
+                          "TimeLimit.truncated": not bool(term)}
+        return infos
+
+    def _out(self, t):
+        return t.cpu().numpy() if self.numpy_io else t
+
+    def close(self):
+        pass
+
+    def seed(self, seed=None):
+        self.seed_value = 0 if seed is None else int(seed)
+        return [self.seed_value + i for i in range(self.n)]
+
+    def get_attr(self, name, indices=None):
+        return [getattr(self, name)] * self.n
+
+    def set_attr(self, name, value, indices=None):
+        setattr(self, name, value)
+
+    def env_method(self, name, *a, indices=None, **kw):
+        return [getattr(self, name)(*a, **kw)]
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False] * self.n
+
+    @property
+    def rate_command(self) -> torch.Tensor:
+        return self.e[L.FD_E_CMD_P:L.FD_E_CMD_R + 1].T

