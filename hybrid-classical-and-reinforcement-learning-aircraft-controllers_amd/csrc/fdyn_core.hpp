@@ -35,20 +35,89 @@ template <> struct M<double> {
     static FD_DEV double fmod(double x, double y) { return ::fmod(x, y); }
     static FD_DEV bool finite(double x) { return ::isfinite(x); }
 };
+// fp32: hand-rolled branch-free kernels.  ocml's sinf/cosf/atan2f inline the Payne-Hanek large-argument path and
+// evaluate it under selects on every call (>1000 VALU per dynamics evaluation, measured); flight angles are bounded
+// (|x| < ~10 rad before the per-step re-wrap), so a two-constant Cody-Waite reduction is exact enough.  Errors are
+// ~1 ulp (<= 1.2e-7 abs on sin/cos), i.e. the same order as the fp32 rounding the variant already accepts.
+namespace fast {
+FD_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }          // v_rcp_f32, 1 ulp
+FD_DEV float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }        // v_sqrt_f32, 1 ulp
+FD_DEV void sincos(float x, float& s, float& c)
+{
+    const float k = __builtin_rintf(x * 0.63661977236758134f);          // nearest multiple of pi/2
+    float r = __builtin_fmaf(k, -1.5707962512969971f, x);               // pi/2 split hi + lo (Cody-Waite)
+    r = __builtin_fmaf(k, -7.5497894158615964e-08f, r);
+    const float z = r * r;
+    // minimax on [-pi/4, pi/4] (Cephes sinf/cosf coefficients)
+    float ps = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = __builtin_fmaf(z, ps, -1.6666654611e-1f);
+    const float sr = __builtin_fmaf(z * r, ps, r);
+    float pc = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = __builtin_fmaf(z, pc, 4.166664568298827e-2f);
+    const float cr = __builtin_fmaf(z * z, pc, __builtin_fmaf(z, -0.5f, 1.0f));
+    const int q = int(k);
+    const bool swap = q & 1;
+    const float ss = swap ? cr : sr, cc = swap ? sr : cr;
+    s = (q & 2) ? -ss : ss;
+    c = ((q + 1) & 2) ? -cc : cc;
+}
+FD_DEV float atan_pos(float a)
+{   // atan for a >= 0 (Cephes atanf: two range reductions + degree-4 polynomial in a^2), branch-free
+    const bool big = a > 2.414213562373095f, mid = a > 0.4142135623730950f;
+    const float num = big ? -1.0f : (mid ? a - 1.0f : a);
+    const float den = big ? a : (mid ? a + 1.0f : 1.0f);
+    const float base = big ? 1.5707963267948966f : (mid ? 0.7853981633974483f : 0.0f);
+    const float t = num * rcp(den);
+    const float z = t * t;
+    float p = __builtin_fmaf(z, 8.05374449538e-2f, -1.38776856032e-1f);
+    p = __builtin_fmaf(z, p, 1.99777106478e-1f);
+    p = __builtin_fmaf(z, p, -3.33329491539e-1f);
+    return base + __builtin_fmaf(p * z, t, t);
+}
+FD_DEV float atan2(float y, float x)
+{
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    const float mx = __builtin_fmaxf(ax, ay), mn = __builtin_fminf(ax, ay);
+    float a = atan_pos(mn * rcp(mx));                                   // in [0, pi/4]; NaN if both are 0
+    a = (mx == 0.0f) ? 0.0f : a;
+    a = (ay > ax) ? 1.5707963267948966f - a : a;
+    a = (x < 0.0f) ? 3.14159265358979323846f - a : a;
+    return __builtin_copysignf(a, y);
+}
+FD_DEV float asin(float x)
+{   // Cephes asinf: |x| > 0.5 -> pi/2 - 2 asin(sqrt((1-|x|)/2))
+    const float ax = __builtin_fabsf(x);
+    const bool big = ax > 0.5f;
+    const float zz = big ? 0.5f * (1.0f - ax) : ax * ax;
+    const float t = big ? sqrt(zz) : ax;
+    float p = __builtin_fmaf(zz, 4.2163199048e-2f, 2.4181311049e-2f);
+    p = __builtin_fmaf(zz, p, 4.5470025998e-2f);
+    p = __builtin_fmaf(zz, p, 7.4953002686e-2f);
+    p = __builtin_fmaf(zz, p, 1.6666752422e-1f);
+    float r = __builtin_fmaf(p * zz, t, t);
+    r = big ? 1.5707963267948966f - 2.0f * r : r;
+    return __builtin_copysignf(r, x);
+}
+}  // namespace fast
+
 template <> struct M<float> {
-    static FD_DEV float sin(float x) { return ::sinf(x); }
-    static FD_DEV float cos(float x) { return ::cosf(x); }
-    static FD_DEV void sincos(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
-    static FD_DEV float tan(float x) { return ::tanf(x); }
-    static FD_DEV float atan2(float y, float x) { return ::atan2f(y, x); }
-    static FD_DEV float asin(float x) { return ::asinf(x); }
-    static FD_DEV float sqrt(float x) { return ::sqrtf(x); }
-    static FD_DEV float exp(float x) { return ::expf(x); }
-    static FD_DEV float abs(float x) { return ::fabsf(x); }
-    static FD_DEV float rint(float x) { return ::rintf(x); }
+    static FD_DEV float sin(float x) { float s, c; fast::sincos(x, s, c); return s; }
+    static FD_DEV float cos(float x) { float s, c; fast::sincos(x, s, c); return c; }
+    static FD_DEV void sincos(float x, float& s, float& c) { fast::sincos(x, s, c); }
+    static FD_DEV float tan(float x) { float s, c; fast::sincos(x, s, c); return s * fast::rcp(c); }
+    static FD_DEV float atan2(float y, float x) { return fast::atan2(y, x); }
+    static FD_DEV float asin(float x) { return fast::asin(x); }
+    static FD_DEV float sqrt(float x) { return fast::sqrt(x); }
+    static FD_DEV float exp(float x) { return __expf(x); }
+    static FD_DEV float abs(float x) { return __builtin_fabsf(x); }
+    static FD_DEV float rint(float x) { return __builtin_rintf(x); }
     static FD_DEV float fmod(float x, float y) { return ::fmodf(x, y); }
-    static FD_DEV bool finite(float x) { return ::isfinite(x); }
+    static FD_DEV bool finite(float x) { return __builtin_isfinite(x); }
 };
+
+// division: IEEE-correct for fp64 (parity), one v_rcp_f32 + multiply for fp32
+FD_DEV double fdiv(double a, double b) { return a / b; }
+FD_DEV float fdiv(float a, float b) { return a * fast::rcp(b); }
 
 // Python / NumPy semantics the reference relies on
 template <typename T> FD_DEV T clipv(T x, T lo, T hi) { return x < lo ? lo : (x > hi ? hi : x); }   // np.clip, NaN stays
@@ -75,6 +144,7 @@ template <typename T> struct Params {
     T damp_roll, damp_pitch, damp_yaw, max_thrust, half_rho, g;
     T min_airspeed, min_u, max_de, max_da, max_dr, thrust_zero_v;
     T max_alpha, max_pitch, max_acc, max_ang_acc;
+    T inv_ixx, inv_iyy, inv_izz;
 
     // `blk` points at one FD_NP-word block staged in LDS (stored as double; narrowed here once per launch)
     FD_DEV void load(const double* blk)
@@ -94,6 +164,7 @@ template <typename T> struct Params {
         max_dr = T(blk[FD_P_MAX_RUDDER_RAD]); thrust_zero_v = T(blk[FD_P_THRUST_ZERO_VELOCITY]);
         max_alpha = T(blk[FD_P_MAX_ALPHA_RAD]); max_pitch = T(blk[FD_P_MAX_PITCH_RAD]);
         max_acc = T(blk[FD_P_MAX_ACCELERATION]); max_ang_acc = T(blk[FD_P_MAX_ANGULAR_ACCELERATION]);
+        inv_ixx = T(1) / ixx; inv_iyy = T(1) / iyy; inv_izz = T(1) / izz;     // used by the fp32 variants only
     }
 };
 
@@ -138,7 +209,8 @@ FD_DEV void dynamics(const Params<T>& P, const Controls<T>& C, const T (&x)[FD_N
     alpha = clipv(alpha, -P.max_alpha, P.max_alpha);                                    // :370
     T sin_alpha, cos_alpha;
     M<T>::sincos(alpha, sin_alpha, cos_alpha);
-    const T beta = M<T>::asin(clipv(v / safe_airspeed, T(-1), T(1)));                   // :376
+    const T inv_V = fdiv(T(1), safe_airspeed);                                          // fp32 only: one v_rcp, reused
+    const T beta = M<T>::asin(clipv(sizeof(T) == 8 ? v / safe_airspeed : v * inv_V, T(-1), T(1)));                   // :376
     const T q_dyn = P.half_rho * (airspeed * airspeed);                                 // :379 (unclamped V)
 
     const T cl = P.cl_0 + P.cl_alpha * alpha + P.cl_de * C.de_rad;                      // :384-390
@@ -149,15 +221,21 @@ FD_DEV void dynamics(const Params<T>& P, const Controls<T>& C, const T (&x)[FD_N
     const T fx_aero = -drag * cos_alpha + lift * sin_alpha;                             // :397-399
     const T fz_aero = -drag * sin_alpha - lift * cos_alpha;
 
-    const T thrust_factor = pymax(T(0), T(1) - airspeed / P.thrust_zero_v);             // :403
+    const T thrust_factor = pymax(T(0), T(1) - fdiv(airspeed, P.thrust_zero_v));             // :403
     const T thrust = P.max_thrust * C.throttle * thrust_factor;
 
     const T fx = fx_aero + thrust + (-P.g * sin_theta) * P.mass;                        // :409-411
     const T fy = side_force + (P.g * cos_theta * sin_phi) * P.mass;
     const T fz = fz_aero + (P.g * cos_theta * cos_phi) * P.mass;
 
-    const T half_span_over_V = P.b / (T(2) * safe_airspeed);                            // :416-417
-    const T half_chord_over_V = P.c / (T(2) * safe_airspeed);
+    T half_span_over_V, half_chord_over_V;                                              // :416-417
+    if constexpr (sizeof(T) == 8) {
+        half_span_over_V = P.b / (T(2) * safe_airspeed);
+        half_chord_over_V = P.c / (T(2) * safe_airspeed);
+    } else {
+        half_span_over_V = (T(0.5) * P.b) * inv_V;
+        half_chord_over_V = (T(0.5) * P.c) * inv_V;
+    }
     const T l_moment = q_S * P.b * (P.cl_da * C.da_rad + P.damp_roll * p * half_span_over_V + P.cl_beta * beta);
     const T m_moment = q_S * P.c * (P.cm_de * C.de_rad + P.cm_alpha * alpha + P.damp_pitch * q * half_chord_over_V);
     const T n_moment = q_S * P.b * (P.cn_dr * C.dr_rad + P.damp_yaw * r * half_span_over_V + P.cn_beta * beta);
@@ -173,22 +251,44 @@ FD_DEV void dynamics(const Params<T>& P, const Controls<T>& C, const T (&x)[FD_N
 
     const T theta_safe = clipv(theta, -P.max_pitch, P.max_pitch);                       // :463-471
     T cos_ts, tan_ts;
-    if (theta_safe == theta) { cos_ts = cos_theta; } else { cos_ts = M<T>::cos(theta_safe); }
-    tan_ts = M<T>::tan(theta_safe);
+    if constexpr (sizeof(T) == 8) {
+        cos_ts = (theta_safe == theta) ? cos_theta : M<T>::cos(theta_safe);
+        tan_ts = M<T>::tan(theta_safe);
+        xd[8] = (sin_phi * q + cos_phi * r) / cos_ts;
+    } else {
+        T sin_ts = sin_theta;
+        cos_ts = cos_theta;
+        if (theta_safe != theta) M<T>::sincos(theta_safe, sin_ts, cos_ts);             // rare: RK4 stage beyond +-85 deg
+        const T inv_c = fast::rcp(cos_ts);
+        tan_ts = sin_ts * inv_c;
+        xd[8] = (sin_phi * q + cos_phi * r) * inv_c;
+    }
     xd[6] = p + sin_phi * tan_ts * q + cos_phi * tan_ts * r;
     xd[7] = cos_phi * q - sin_phi * r;
-    xd[8] = (sin_phi * q + cos_phi * r) / cos_ts;
 
-    xd[9] = (l_moment - (P.izz - P.iyy) * q * r) / P.ixx;                               // :474-482
-    xd[10] = (m_moment - (P.ixx - P.izz) * p * r) / P.iyy;
-    xd[11] = (n_moment - (P.iyy - P.ixx) * p * q) / P.izz;
+    if constexpr (sizeof(T) == 8) {                                                     // :474-482
+        xd[9] = (l_moment - (P.izz - P.iyy) * q * r) / P.ixx;
+        xd[10] = (m_moment - (P.ixx - P.izz) * p * r) / P.iyy;
+        xd[11] = (n_moment - (P.iyy - P.ixx) * p * q) / P.izz;
+    } else {
+        xd[9] = (l_moment - (P.izz - P.iyy) * q * r) * P.inv_ixx;
+        xd[10] = (m_moment - (P.ixx - P.izz) * p * r) * P.inv_iyy;
+        xd[11] = (n_moment - (P.iyy - P.ixx) * p * q) * P.inv_izz;
+    }
 
 #pragma unroll
     for (int i = 9; i < 12; ++i) xd[i] = clipv(xd[i], -P.max_ang_acc, P.max_ang_acc);  // :485-490
 #pragma unroll
     for (int i = 3; i < 6; ++i) xd[i] = clipv(xd[i], -P.max_acc, P.max_acc);
+    // :496-501 non-finite derivatives -> 0.  Every derivative is bounded (clamped or O(100)), so their sum is finite
+    // iff each one is: one class test on the sum guards a rare, wave-uniformly-skipped fix-up branch.
+    T acc = xd[0];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) xd[i] = M<T>::finite(xd[i]) ? xd[i] : T(0);            // :496-501 (branch-free)
+    for (int i = 1; i < 12; ++i) acc += xd[i];
+    if (!M<T>::finite(acc)) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) xd[i] = M<T>::finite(xd[i]) ? xd[i] : T(0);
+    }
 }
 
 // roll / yaw re-wrap of the stored state (simplified_6dof.py:266,270).  The f64 variant keeps the
@@ -243,8 +343,13 @@ FD_DEV void rk4_step(const Params<T>& P, const Limits<S>& Lm, const Controls<T>&
         x[2] = S(0);
         x[5] = x[5] > S(0) ? x[5] : S(0);
     }
+    S accs = x[0];                                                                     // :286-291, same trick
 #pragma unroll
-    for (int i = 0; i < 12; ++i) x[i] = M<S>::finite(x[i]) ? x[i] : S(0);              // :286-291
+    for (int i = 1; i < 12; ++i) accs += x[i];
+    if (!M<S>::finite(accs)) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) x[i] = M<S>::finite(x[i]) ? x[i] : S(0);
+    }
 }
 
 // ----- get_state's derived scalars: simplified_6dof.py:295-331 + _body_to_ned :505-530 -------------------

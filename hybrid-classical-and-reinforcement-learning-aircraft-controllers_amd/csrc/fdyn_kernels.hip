@@ -386,8 +386,8 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
                      const double* __restrict__ pool, int pool_depth, uint64_t seed, int auto_reset,
                      float* __restrict__ obs_out /*[n][18]*/, float* __restrict__ reward_f32, S* __restrict__ reward_full,
                      uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
-                     int32_t* __restrict__ ev_count, int32_t* __restrict__ ev_int, float* __restrict__ ev_flt, int ev_cap,
-                     int64_t n)
+                     int32_t* __restrict__ ev_count, int32_t* __restrict__ ev_count_next, int32_t* __restrict__ ev_int,
+                     float* __restrict__ ev_flt, int ev_cap, int64_t n)
 {
     __shared__ double s_params[FD_MAX_TYPES * FD_NP];
     __shared__ float s_tile[FD_BLOCK / FD_WAVE][FD_WAVE * (FD_OBS_DIM + 1)];
@@ -406,6 +406,9 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
     const bool active = i < n;
     EnvConsts<S> ec;
     load_env_consts<S>(EC, ec);
+    // double-buffered event counter: this launch appends to *ev_count and clears the OTHER slot for the next
+    // launch, so the per-step host-side memset disappears from the stream
+    if (ev_count_next && blockIdx.x == 0 && threadIdx.x == 0) *ev_count_next = 0;
 
     float o[FD_OBS_DIM];
 #pragma unroll
@@ -663,8 +666,8 @@ FD_DEFINE_CASCADE(fdyn_cascade_step_f32, float, float)
                                     float* actions_out, const S* rw_delta, const double* pool, int pool_depth, \
                                     uint64_t seed, int auto_reset, float* obs_out, float* reward_f32,        \
                                     S* reward_full, uint8_t* terminated, uint8_t* truncated,                 \
-                                    int32_t* ev_count, int32_t* ev_int, float* ev_flt, int ev_cap,           \
-                                    int64_t n, void* stream)                                                 \
+                                    int32_t* ev_count, int32_t* ev_count_next, int32_t* ev_int,              \
+                                    float* ev_flt, int ev_cap, int64_t n, void* stream)                      \
     {                                                                                                        \
         FD_CHECK_COMMON(n, n_types)                                                                          \
         if (pool && pool_depth < 1) return FDYN_ERR_BAD_SIZE;                                                \
@@ -674,7 +677,8 @@ FD_DEFINE_CASCADE(fdyn_cascade_step_f32, float, float)
         hipLaunchKernelGGL((rate_env_step_kernel<S, T>), dim3(grid_for(n)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
                            x, e, ei, type, params, n_types, env_consts, actions, pid_state, pid_cfg,         \
                            casc_consts, actions_out, rw_delta, pool, pool_depth, seed, auto_reset, obs_out,  \
-                           reward_f32, reward_full, terminated, truncated, ev_count, ev_int, ev_flt, ev_cap, n); \
+                           reward_f32, reward_full, terminated, truncated, ev_count, ev_count_next, ev_int, ev_flt,  \
+                           ev_cap, n);                                                                       \
         return launch_status();                                                                              \
     }
 FD_DEFINE_ENV(f64, double, double)

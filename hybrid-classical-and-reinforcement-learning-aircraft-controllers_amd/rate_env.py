@@ -51,7 +51,9 @@ class GpuRateVecEnv:
         self.actions_taken = torch.zeros((n, L.FD_ACT_DIM), dtype=torch.float32, device=dev)
         # compacted episode-end records
         self.ev_cap = int(event_capacity if event_capacity is not None else n)
-        self.ev_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._ev_counts = torch.zeros(2, dtype=torch.int32, device=dev)      # ping-pong counters (kernel clears the other)
+        self._ev_slot = 0
+        self.ev_count = self._ev_counts[0:1]
         self.ev_int = torch.zeros((max(self.ev_cap, 1), L.FD_EV_NI), dtype=torch.int32, device=dev)
         self.ev_flt = torch.zeros((max(self.ev_cap, 1), L.FD_EV_NF), dtype=torch.float32, device=dev)
         # fused PID demonstrator (learned_controllers/utils/pid_demonstrations.py:41-77)
@@ -87,14 +89,15 @@ class GpuRateVecEnv:
         if actions is not None:
             actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
             assert actions.shape == (self.n, L.FD_ACT_DIM)
-        self.ev_count.zero_()
+        cur, nxt = self._ev_counts[self._ev_slot:self._ev_slot + 1], self._ev_counts[1 - self._ev_slot:2 - self._ev_slot]
+        self.ev_count, self._ev_slot = cur, 1 - self._ev_slot
         rc = self._step_fn(_lib.ptr(self.x), _lib.ptr(self.e), _lib.ptr(self.ei), _lib.ptr(self.type_index),
                            _lib.ptr(self.params), self.n_types, _lib.ptr(self.env_consts), _lib.ptr(actions),
                            _lib.ptr(self.pid_state), _lib.ptr(self.pid_cfg), _lib.ptr(self.casc_consts),
                            _lib.ptr(self.actions_taken), _lib.ptr(rw_delta), _lib.ptr(self.pool), self.pool_depth,
                            self.seed_value, int(auto_reset), _lib.ptr(self.obs), _lib.ptr(self.rewards),
                            _lib.ptr(self.rewards_full), _lib.ptr(self.terminated), _lib.ptr(self.truncated),
-                           _lib.ptr(self.ev_count), _lib.ptr(self.ev_int), _lib.ptr(self.ev_flt), self.ev_cap,
+                           cur.data_ptr(), nxt.data_ptr(), _lib.ptr(self.ev_int), _lib.ptr(self.ev_flt), self.ev_cap,
                            self.n, _lib.current_stream())
         _lib.check(rc, "RateControlEnv.step")
         return self.obs, self.rewards, self.terminated, self.truncated

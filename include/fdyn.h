@@ -96,8 +96,10 @@ int fdyn_cascade_step_f32(float* x, float* pid_state, int32_t* wp_idx, const uin
  *        rw_delta [3][n] this step's random-walk deltas (parity mode) or NULL
  *        auto_reset != 0: envs that end are reset in-kernel and obs_out holds the post-reset observation
  *        reward_f32 [n] / reward_full [n] (either may be NULL) ; terminated, truncated [n] uint8
- *        ev_count [1] int32 (caller zeroes), ev_int [ev_cap][FD_EV_NI], ev_flt [ev_cap][FD_EV_NF]: compacted
- *        episode-end records (env id, length, terminated | return, terminal observation); NULL = no records  */
+ *        ev_count [1] int32 (must be 0 on entry), ev_int [ev_cap][FD_EV_NI], ev_flt [ev_cap][FD_EV_NF]: compacted
+ *        episode-end records (env id, length, terminated | return, terminal observation); NULL = no records.
+ *        ev_count_next [1] or NULL: a second counter this launch clears, so two counters can be ping-ponged
+ *        across steps without a memset on the stream                                                         */
 #define FDYN_DECLARE_ENV(SUFFIX, S)                                                                             \
     int fdyn_rate_env_reset_##SUFFIX(S* x, S* e, int32_t* ei, float* pid_state, const uint8_t* mask,            \
                                      const double* env_consts, const double* pool, int pool_depth,              \
@@ -108,8 +110,8 @@ int fdyn_cascade_step_f32(float* x, float* pid_state, int32_t* wp_idx, const uin
                                     float* actions_out, const S* rw_delta, const double* pool, int pool_depth,  \
                                     uint64_t seed, int auto_reset, float* obs_out, float* reward_f32,           \
                                     S* reward_full, uint8_t* terminated, uint8_t* truncated,                    \
-                                    int32_t* ev_count, int32_t* ev_int, float* ev_flt, int ev_cap,              \
-                                    int64_t n, void* stream);
+                                    int32_t* ev_count, int32_t* ev_count_next, int32_t* ev_int,                 \
+                                    float* ev_flt, int ev_cap, int64_t n, void* stream);
 FDYN_DECLARE_ENV(f64, double)
 FDYN_DECLARE_ENV(mixed, double)
 FDYN_DECLARE_ENV(f32, float)
