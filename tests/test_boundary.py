@@ -1,0 +1,128 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports exactly what include/fdyn.h declares,
+the host mirror keeps the reference's interface, and the product never touches the oracle or falls back to a CPU path.
+No compute calls (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+import hcrl_amd
+from hcrl_amd import _lib, layout as L, config as cfgmod, samplers
+from hcrl_amd.flight_types import AircraftState, ControlSurfaces, ControllerConfig, Waypoint
+from hcrl_amd.params import AircraftParams
+
+PKG = os.path.join(REPO, "hybrid-classical-and-reinforcement-learning-aircraft-controllers_amd")
+
+
+def _declared_symbols():
+    src = open(os.path.join(REPO, "include", "fdyn.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set(re.findall(r"\bint\s+(fdyn_\w+)\s*\(", src))
+    # the env entry points are declared through FDYN_DECLARE_ENV(SUFFIX, S)
+    names = {n for n in names if "##" not in n}
+    for suffix in re.findall(r"FDYN_DECLARE_ENV\((\w+),", src):
+        if suffix != "SUFFIX":
+            names |= {f"fdyn_rate_env_reset_{suffix}", f"fdyn_rate_env_step_{suffix}"}
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.check_call([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=REPO)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 17
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/fdyn.h but not exported"
+    assert declared == set(_lib.SIGNATURES), "host binding table and header drifted apart"
+    assert lib.fdyn_abi_version() == 1
+
+
+def test_code_object_is_gfx950():
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", _lib.LIB_PATH], capture_output=True,
+                         text=True).stdout
+    assert "gfx950" in out
+
+
+def test_num_substeps_matches_python_int_truncation():
+    lib = _lib.load()
+    for dt, dtp in [(0.03, 0.001), (0.02, 0.001), (0.0005, 0.001), (0.07, 0.01), (0.02, 0.003), (0.1, 0.001), (0.029, 0.001)]:
+        assert lib.fdyn_num_substeps(dt, dtp) == max(1, int(dt / dtp))     # simulation_backend.py:95
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from hcrl_amd.fleet import BatchedSixDOF
+    from hcrl_amd.rate_env import GpuRateVecEnv
+    with pytest.raises(_lib.FdynError):
+        BatchedSixDOF(4)
+    with pytest.raises(_lib.FdynError):
+        GpuRateVecEnv(4)
+
+
+def test_product_never_imports_the_oracle():
+    for root, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f
+                assert "liboracle" not in text and "flight_oracle" not in text, f
+    for f in os.listdir(os.path.join(REPO, "include")):
+        assert "oracle" not in open(os.path.join(REPO, "include", f)).read().lower() or f == "fdyn_layout.h"
+
+
+def test_layout_module_mirrors_header():
+    assert L.FD_NX == 12 and L.FD_NU == 4 and L.FD_OBS_DIM == 18 and L.FD_ACT_DIM == 4
+    assert L.FD_NP_USED <= L.FD_NP and L.FD_NPID == 9 and L.FD_NPC == 8 and L.FD_NPS == 3
+    assert L.FD_EV_NF == 1 + L.FD_OBS_DIM
+
+
+def test_types_keep_reference_conventions():
+    s = ControlSurfaces(elevator=0.1, aileron=-0.2, rudder=0.3, throttle=0.7)
+    assert np.allclose(s.to_array(), [0.1, -0.2, 0.3, 0.7])                     # types.py:189-201
+    assert ControlSurfaces.from_array(s.to_array()) == s
+    w = Waypoint.from_altitude(10, 20, 100, speed=15)
+    assert w.down == -100 and w.altitude == 100
+    st = AircraftState.from_vector(np.arange(12.0))
+    assert st.north == 0 and st.p == 9 and st.yaw == 8 and np.array_equal(st.to_vector(), np.arange(12.0))
+    c = ControllerConfig()
+    assert (c.roll_rate_gains.kp, c.roll_rate_gains.i_limit, c.max_yaw_rate) == (1.3, 25.0, 160.0)
+
+
+def test_params_validation_mirrors_reference():
+    for kw in ({"mass": 0}, {"inertia_yy": -1}, {"wing_area": 0}, {"air_density": 11}, {"gravity": 0}, {"max_thrust": -1}):
+        with pytest.raises(ValueError):
+            AircraftParams(**kw)                                                  # simplified_6dof.py:119-143
+
+
+def test_cascade_tables_alias_the_configs_like_the_reference():
+    fc = cfgmod.load_controller_config("cascaded_pid.yaml")
+    t = cfgmod.pid_table(ControllerConfig(), fc)
+    C = cfgmod.cascade_consts(ControllerConfig(), fc, guidance_type="PP")
+    # attitude/rate limits come from the LEGACY config (180/180/160 deg/s, 30/30 deg), not the YAML (200/100/60, 30/20)
+    assert np.isclose(C[L.FD_C_MAX_YAW_RATE], np.radians(160)) and np.isclose(C[L.FD_C_MAX_PITCH], np.radians(30))
+    assert t[L.FD_PID_ATT_ROLL, L.FD_PC_OUT_MAX] == np.float32(np.radians(180))
+    assert t[L.FD_PID_HEADING, L.FD_PC_INT_MAX] == 25.0 and t[L.FD_PID_HEADING, L.FD_PC_OUT_MAX] == np.float32(np.radians(25))
+    assert t[L.FD_PID_ENERGY, L.FD_PC_INT_MAX] == 10.0 and t[L.FD_PID_BALANCE, L.FD_PC_INT_MAX] == 5.0
+    assert np.isclose(C[L.FD_C_MAX_PITCH_CMD_RAD], np.radians(10)) and C[L.FD_C_GUIDANCE_TYPE] == L.FD_GUIDANCE_PP
+    assert cfgmod.cascade_consts(guidance_type="whatever")[L.FD_C_GUIDANCE_TYPE] == L.FD_GUIDANCE_DEFAULT
+    with pytest.raises(ValueError):
+        cfgmod.waypoint_table([])                                                 # mission_planner.py:60-61
+
+
+def test_reset_pool_follows_reference_stream_order():
+    pool = samplers.presample_reset_pool([42, 43], 3, "easy", "step")
+    assert pool.shape == (2, 3, L.FD_NR)
+    # RateControlEnv(easy, step, rng_seed=42).reset(seed=42) -> this command and these initial conditions
+    assert np.allclose(pool[0, 0, L.FD_R_CMD0:L.FD_R_CMD2 + 1], [-0.90996233, -0.79713236, -0.34282152], atol=1e-8)
+    assert np.allclose(pool[0, 0, [L.FD_R_AIRSPEED, L.FD_R_ALTITUDE, L.FD_R_ROLL, L.FD_R_PITCH, L.FD_R_YAW]],
+                       [20.6181, 192.6071, 0.1214717, 0.05165746, 0.980294], rtol=1e-6)
+    ec = samplers.env_consts("easy", 10.0, 0.02, "step")
+    assert ec[L.FD_EC_MAX_STEPS] == 500 and ec[L.FD_EC_DIFFICULTY_SCALE] == 0.3
