@@ -27,8 +27,8 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable with a float4 copy)
 FP32_VECTOR_PEAK_TFLOPS = 157.3
 # SURVEY §8(d) algorithmic bytes per unit (fp32 words) and flops per unit
-ALG_BYTES = {"env": 300.0, "env_pid": 300.0, "physics": 112.0, "cascade": 344.0}
-ALG_FLOPS = {"env": 40.0e3, "env_pid": 40.0e3 + 0.05e3, "physics": 2.0e3, "cascade": 2.4e3}
+ALG_BYTES = {"env": 300.0, "env_pid": 300.0, "physics": 112.0, "cascade": 344.0, "rollout": 300.0, "train": 300.0}
+ALG_FLOPS = {"env": 40.0e3, "env_pid": 40.0e3 + 0.05e3, "physics": 2.0e3, "cascade": 2.4e3, "rollout": 40.0e3, "train": 40.0e3}
 
 
 def parse():
@@ -36,13 +36,17 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--workload", default="env", choices=["env", "env_pid", "physics", "cascade"])
+    ap.add_argument("--workload", default="env", choices=["env", "env_pid", "physics", "cascade", "rollout", "train"])
     ap.add_argument("--precision", default="mixed", choices=["f64", "mixed", "f32"])
     ap.add_argument("--batch", type=int, default=65536, help="envs / aircraft per GPU")
     ap.add_argument("--graph", type=int, default=1, help="replay the step loop from a hipGraph (1) or launch eagerly (0)")
     ap.add_argument("--graph-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--policy-dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--ppo-steps", type=int, default=16, help="rollout length per PPO iteration (train workload)")
+    ap.add_argument("--ppo-epochs", type=int, default=2)
+    ap.add_argument("--ppo-minibatches", type=int, default=8)
     return ap.parse_args()
 
 
@@ -70,7 +74,23 @@ class Workload:
         self.kind, self.n = w, n
         seed = 1000 * rank
         dev = torch.device("cuda", torch.cuda.current_device())
-        if w in ("env", "env_pid"):
+        if w in ("rollout", "train"):
+            from hcrl_amd.policy import RateLSTMPolicy
+            from hcrl_amd.ppo import PPOConfig, RecurrentPPO
+            self.env = GpuRateVecEnv(n, "easy", 10.0, 0.02, "step", seed=seed, precision=prec, sampling="device")
+            pol = RateLSTMPolicy(compute_dtype=torch.bfloat16 if args.policy_dtype == "bf16" else None)
+            cfg = PPOConfig(n_steps=args.ppo_steps, n_epochs=args.ppo_epochs, n_minibatches=args.ppo_minibatches)
+            self.ppo = RecurrentPPO(self.env, pol, cfg, seed=42)
+            self.policy_flops = pol.flops_per_env_step()
+            if w == "rollout":
+                self.units_per_step = n
+                self.desc = (f"PPO rollout step: LSTM policy inference ({args.policy_dtype} GEMMs, {pol.num_parameters()} params) "
+                             f"+ fused rate_env_step, {n} envs/GPU, easy/step")
+            else:
+                self.units_per_step = n * args.ppo_steps
+                self.desc = (f"full PPO iteration: {args.ppo_steps}-step rollout + GAE + {args.ppo_epochs} epochs x "
+                             f"{args.ppo_minibatches} minibatches BPTT ({args.policy_dtype}), flat-gradient all-reduce, {n} envs/GPU")
+        elif w in ("env", "env_pid"):
             self.env = GpuRateVecEnv(n, "medium", 10.0, 0.02, "step", seed=seed, precision=prec, sampling="device")
             self.env.reset()
             g = torch.Generator(device=dev).manual_seed(seed + 1)
@@ -106,8 +126,20 @@ class Workload:
             self.desc = (f"5-level cascade + 1 RK4 per 10 ms control step, {self.inner} control steps per launch, "
                          f"{n} aircraft/GPU, square mission (restarts)")
 
+    @torch.no_grad()
+    def _rollout_step(self):
+        p = self.ppo
+        a, _v, _lp, p.states = p.policy.step(p.obs, p.states, p.episode_start)
+        obs, _r, term, trunc = self.env.step_device(a)
+        p.obs, p.episode_start = obs, (term | trunc).float()
+
     def step(self, k):
-        if self.kind == "env":
+        if self.kind == "rollout":
+            self._rollout_step()
+        elif self.kind == "train":
+            self.ppo.collect_rollout()
+            self.ppo.update()
+        elif self.kind == "env":
             self.env.step_device(self.actions[k % len(self.actions)])
         elif self.kind == "env_pid":
             self.env.step_device(None)
@@ -122,7 +154,7 @@ def timed_region(wl, args, world):
     K, W = args.steps, args.warmup
     stream = torch.cuda.current_stream()
     graph, gsteps = None, 0
-    if args.graph and K >= 2:
+    if args.graph and K >= 2 and args.workload in ("env", "env_pid", "physics", "cascade"):
         gsteps = max(2, min(args.graph_steps, K) // 2 * 2)          # even: the event counters ping-pong
         side = torch.cuda.Stream()
         side.wait_stream(stream)
@@ -240,6 +272,12 @@ def main():
                     "peak_tflops": FP32_VECTOR_PEAK_TFLOPS,
                     "frac": ALG_FLOPS[args.workload] * wl.units_per_step / per_launch_s / 1e12 / FP32_VECTOR_PEAK_TFLOPS},
     }
+    if args.workload in ("rollout", "train"):
+        mult = 1.0 if args.workload == "rollout" else (1.0 + 3.0 * args.ppo_epochs)      # fwd, or fwd + epochs x (fwd+bwd)
+        pf = wl.policy_flops * mult * wl.units_per_step / (wall / K) / 1e12
+        out["policy"] = {"flops_per_env_step_fwd": wl.policy_flops, "achieved_tflops": pf, "dtype": args.policy_dtype,
+                         "peak_tflops_dense": 2500.0 if args.policy_dtype == "bf16" else 157.3,
+                         "frac": pf / (2500.0 if args.policy_dtype == "bf16" else 157.3)}
     if world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(args)

@@ -1,0 +1,199 @@
+"""PPO + LSTM rate-controller policy in PyTorch-ROCm.
+
+Architecture = what the reference's `train_rate.py:115-147` builds: sb3_contrib `RecurrentPPO("MlpLstmPolicy")` with
+`LSTMPolicy.get_policy_kwargs()` (learned_controllers/networks/lstm_policy.py:107-136):
+
+  features extractor (lstm_policy.py:13-97): Linear(18,128)+ReLU -> nn.LSTM(128,256,num_layers=2) -> Linear(256,128)+ReLU
+      NOTE the reference calls `self.lstm(embedded)` on a length-1 sequence WITHOUT carried state (:75-92), so this
+      2-layer LSTM always starts from h=c=0: the W_hh products and the forget gate vanish and each layer reduces to
+      h = sigmoid(o) * tanh(sigmoid(i) * tanh(g)) with gates = x W_ih^T + b_ih + b_hh.  We keep nn.LSTM's parameter
+      tensors (checkpoint-compatible) but evaluate that closed form: one GEMM per layer instead of two.
+  actor LSTM / critic LSTM (sb3_contrib defaults): nn.LSTM(128, 256, 1) each, state carried across env steps and
+      zeroed at episode starts -- THE recurrence, and the only dense contraction with a sequential dependency;
+  mlp_extractor: pi [128, 64], vf [128, 64], ReLU;  action_net Linear(64,4), value_net Linear(64,1), log_std (4).
+SB3 / sb3_contrib are third-party and absent here: numerics parity with them is unpinned; shapes,
+parameter names and hyper-parameters follow the reference's config (learned_controllers/config/ppo_lstm.yaml:38-58).
+
+Every matmul is a `[B, K] x [K, 4H]` GEMM that rocBLAS/hipBLASLt runs on MFMA; with `compute_dtype=torch.bfloat16`
+the GEMMs run in bf16 with fp32 accumulate (autocast), the cell state and the PPO loss stay fp32.
+"""
+import math
+from typing import NamedTuple, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+OBS_DIM, ACT_DIM = 18, 4
+
+
+class RNNStates(NamedTuple):
+    pi_h: torch.Tensor   # [B, H]
+    pi_c: torch.Tensor
+    vf_h: torch.Tensor
+    vf_c: torch.Tensor
+
+    def detach(self):
+        return RNNStates(*(t.detach() for t in self))
+
+    def masked(self, keep):
+        """keep = 1 - episode_start, [B] -> zero the state of envs that start a new episode."""
+        k = keep.unsqueeze(-1)
+        return RNNStates(*(t * k for t in self))
+
+    def index(self, idx):
+        return RNNStates(*(t[idx] for t in self))
+
+
+def _lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh):
+    """One LSTM step as ONE fused GEMM over the concatenated [x, h] (K = in + H) -- PyTorch gate order i, f, g, o."""
+    gates = F.linear(torch.cat([x, h.to(x.dtype)], dim=-1), torch.cat([w_ih, w_hh], dim=1), b_ih + b_hh)
+    i, f, g, o = gates.float().chunk(4, dim=-1)
+    c_new = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+    h_new = torch.sigmoid(o) * torch.tanh(c_new)
+    return h_new, c_new
+
+
+def _lstm_zero_state_layer(x, w_ih, b_ih, b_hh):
+    gates = F.linear(x, w_ih, b_ih + b_hh)
+    i, _f, g, o = gates.float().chunk(4, dim=-1)
+    c = torch.sigmoid(i) * torch.tanh(g)
+    return torch.sigmoid(o) * torch.tanh(c)
+
+
+class LSTMFeaturesExtractor(nn.Module):
+    def __init__(self, obs_dim: int = OBS_DIM, features_dim: int = 128, lstm_hidden_size: int = 256, n_lstm_layers: int = 2):
+        super().__init__()
+        self.features_dim = features_dim
+        self.embedding = nn.Sequential(nn.Linear(obs_dim, 128), nn.ReLU())
+        self.lstm = nn.LSTM(input_size=128, hidden_size=lstm_hidden_size, num_layers=n_lstm_layers, batch_first=True)
+        self.output_proj = nn.Sequential(nn.Linear(lstm_hidden_size, features_dim), nn.ReLU())
+
+    def forward(self, obs):
+        x = self.embedding(obs)
+        for layer in range(self.lstm.num_layers):
+            x = _lstm_zero_state_layer(x, getattr(self.lstm, f"weight_ih_l{layer}"), getattr(self.lstm, f"bias_ih_l{layer}"),
+                                       getattr(self.lstm, f"bias_hh_l{layer}")).to(x.dtype)
+        return self.output_proj(x)
+
+
+def _mlp(sizes):
+    layers = []
+    for a, b in zip(sizes[:-1], sizes[1:]):
+        layers += [nn.Linear(a, b), nn.ReLU()]
+    return nn.Sequential(*layers)
+
+
+class RateLSTMPolicy(nn.Module):
+    """Actor-critic with separate actor/critic LSTMs (sb3_contrib RecurrentActorCriticPolicy defaults)."""
+
+    def __init__(self, features_dim: int = 128, lstm_hidden_size: int = 256, n_lstm_layers: int = 2,
+                 policy_lstm_hidden: int = 256, net_arch_pi=(128, 64), net_arch_vf=(128, 64), use_lstm: bool = True,
+                 mlp_net_arch=(256, 128, 64), compute_dtype: Optional[torch.dtype] = None):
+        super().__init__()
+        self.use_lstm, self.hidden, self.compute_dtype = use_lstm, policy_lstm_hidden, compute_dtype
+        if use_lstm:
+            self.features_extractor = LSTMFeaturesExtractor(OBS_DIM, features_dim, lstm_hidden_size, n_lstm_layers)
+            self.lstm_actor = nn.LSTM(features_dim, policy_lstm_hidden, 1)
+            self.lstm_critic = nn.LSTM(features_dim, policy_lstm_hidden, 1)
+            self.pi_net = _mlp([policy_lstm_hidden, *net_arch_pi])
+            self.vf_net = _mlp([policy_lstm_hidden, *net_arch_vf])
+            last_pi, last_vf = net_arch_pi[-1], net_arch_vf[-1]
+        else:   # SimpleMLPPolicy (lstm_policy.py:139-164): PPO("MlpPolicy"), pi = vf = mlp.net_arch
+            self.features_extractor = nn.Identity()
+            self.pi_net = _mlp([OBS_DIM, *mlp_net_arch])
+            self.vf_net = _mlp([OBS_DIM, *mlp_net_arch])
+            last_pi = last_vf = mlp_net_arch[-1]
+        self.action_net = nn.Linear(last_pi, ACT_DIM)
+        self.value_net = nn.Linear(last_vf, 1)
+        self.log_std = nn.Parameter(torch.zeros(ACT_DIM))
+        self._init_weights()
+
+    def _init_weights(self):
+        # SB3 ortho_init: sqrt(2) for the trunks, 0.01 for the action head, 1 for the value head
+        for mod, gain in ((self.features_extractor, math.sqrt(2)), (self.pi_net, math.sqrt(2)), (self.vf_net, math.sqrt(2)),
+                          (self.action_net, 0.01), (self.value_net, 1.0)):
+            for m in mod.modules():
+                if isinstance(m, nn.Linear):
+                    nn.init.orthogonal_(m.weight, gain=gain)
+                    nn.init.zeros_(m.bias)
+
+    def initial_state(self, batch: int, device=None) -> RNNStates:
+        z = lambda: torch.zeros(batch, self.hidden, device=device or self.log_std.device)  # noqa: E731
+        return RNNStates(z(), z(), z(), z())
+
+    # ---- single env step (rollout) --------------------------------------------------------------------------
+    def _core(self, obs, states: RNNStates):
+        feats = self.features_extractor(obs)
+        if not self.use_lstm:
+            return self.pi_net(feats), self.vf_net(feats), states
+        la, lc = self.lstm_actor, self.lstm_critic
+        pi_h, pi_c = _lstm_cell(feats, states.pi_h, states.pi_c, la.weight_ih_l0, la.weight_hh_l0, la.bias_ih_l0, la.bias_hh_l0)
+        vf_h, vf_c = _lstm_cell(feats, states.vf_h, states.vf_c, lc.weight_ih_l0, lc.weight_hh_l0, lc.bias_ih_l0, lc.bias_hh_l0)
+        return self.pi_net(pi_h.to(feats.dtype)), self.vf_net(vf_h.to(feats.dtype)), RNNStates(pi_h, pi_c, vf_h, vf_c)
+
+    def step(self, obs, states: RNNStates, episode_start, deterministic: bool = False):
+        """obs [B,18], episode_start [B] (1 where the env was just reset) -> actions, values, log_probs, new states."""
+        states = states.masked(1.0 - episode_start.float())
+        with torch.autocast(obs.device.type, dtype=self.compute_dtype, enabled=self.compute_dtype is not None):
+            lat_pi, lat_vf, new_states = self._core(obs, states)
+            mean = self.action_net(lat_pi).float()
+            value = self.value_net(lat_vf).float().squeeze(-1)
+        std = self.log_std.exp()
+        actions = mean if deterministic else mean + std * torch.randn_like(mean)
+        return actions, value, self._log_prob(actions, mean), new_states
+
+    def _log_prob(self, actions, mean):
+        var = (2 * self.log_std).exp()
+        return (-((actions - mean) ** 2) / (2 * var) - self.log_std - 0.5 * math.log(2 * math.pi)).sum(-1)
+
+    def entropy(self):
+        return (0.5 + 0.5 * math.log(2 * math.pi) + self.log_std).sum()
+
+    # ---- sequence evaluation (PPO update, BPTT over T) ----------------------------------------------------------
+    def evaluate_sequence(self, obs, actions, episode_starts, states: RNNStates) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """obs [T,B,18], actions [T,B,4], episode_starts [T,B], states at t=0 -> values [T,B], log_probs [T,B], entropy."""
+        T = obs.shape[0]
+        values, logps = [], []
+        with torch.autocast(obs.device.type, dtype=self.compute_dtype, enabled=self.compute_dtype is not None):
+            if not self.use_lstm:
+                lat_pi, lat_vf, _ = self._core(obs.reshape(-1, OBS_DIM), states)
+                mean = self.action_net(lat_pi).float().view(T, -1, ACT_DIM)
+                return self.value_net(lat_vf).float().view(T, -1), self._log_prob(actions, mean), self.entropy()
+            # the zero-state feature extractor has no time dependence: run it for all T*B rows in one set of GEMMs
+            feats = self.features_extractor(obs.reshape(-1, OBS_DIM)).view(T, -1, self.features_extractor.features_dim)
+            la, lc = self.lstm_actor, self.lstm_critic
+            wa, ba = torch.cat([la.weight_ih_l0, la.weight_hh_l0], 1), la.bias_ih_l0 + la.bias_hh_l0
+            wc, bc = torch.cat([lc.weight_ih_l0, lc.weight_hh_l0], 1), lc.bias_ih_l0 + lc.bias_hh_l0
+            pi_hs, vf_hs = [], []
+            pi_h, pi_c, vf_h, vf_c = states
+            for t in range(T):
+                keep = (1.0 - episode_starts[t].float()).unsqueeze(-1)
+                pi_h, pi_c, vf_h, vf_c = pi_h * keep, pi_c * keep, vf_h * keep, vf_c * keep
+                x = feats[t]
+                ga = F.linear(torch.cat([x, pi_h.to(x.dtype)], -1), wa, ba).float()
+                gc = F.linear(torch.cat([x, vf_h.to(x.dtype)], -1), wc, bc).float()
+                i, f, g, o = ga.chunk(4, -1)
+                pi_c = torch.sigmoid(f) * pi_c + torch.sigmoid(i) * torch.tanh(g)
+                pi_h = torch.sigmoid(o) * torch.tanh(pi_c)
+                i, f, g, o = gc.chunk(4, -1)
+                vf_c = torch.sigmoid(f) * vf_c + torch.sigmoid(i) * torch.tanh(g)
+                vf_h = torch.sigmoid(o) * torch.tanh(vf_c)
+                pi_hs.append(pi_h); vf_hs.append(vf_h)
+            pi_seq, vf_seq = torch.stack(pi_hs).to(feats.dtype), torch.stack(vf_hs).to(feats.dtype)
+            mean = self.action_net(self.pi_net(pi_seq)).float()
+            values = self.value_net(self.vf_net(vf_seq)).float().squeeze(-1)
+        return values, self._log_prob(actions, mean), self.entropy()
+
+    def predict_values(self, obs, states: RNNStates, episode_start):
+        return self.step(obs, states, episode_start, deterministic=True)[1]
+
+    def num_parameters(self):
+        return sum(p.numel() for p in self.parameters())
+
+    @staticmethod
+    def flops_per_env_step(use_lstm: bool = True) -> float:
+        """Forward multiply-add flops per env step (2*K*N per row): embedding + 2 zero-state layers + proj + 2 LSTMs + heads."""
+        if not use_lstm:
+            return 2.0 * 2 * (18 * 256 + 256 * 128 + 128 * 64) + 2 * (64 * 4 + 64)
+        return 2.0 * (18 * 128 + 128 * 1024 + 256 * 1024 + 256 * 128 + 2 * (384 * 1024) + 2 * (256 * 128 + 128 * 64) + 64 * 4 + 64)

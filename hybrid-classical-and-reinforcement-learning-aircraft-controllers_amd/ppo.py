@@ -1,0 +1,220 @@
+"""Recurrent PPO over the device-resident vec-env, data-parallel across GPUs with one flat gradient all-reduce.
+
+What it stands in for: the `RecurrentPPO(...)`/`PPO(...)` + `model.learn(...)` calls of the reference's trainers
+(learned_controllers/train_rate.py:128-180, train_overnight.py:142-224) with the hyper-parameters of
+learned_controllers/config/ppo_lstm.yaml:38-58 (lr 3e-4, gamma 0.99, lambda 0.95, clip 0.2, ent 0.01, vf 0.5,
+max-grad-norm 0.5, n_epochs 10).  SB3 itself is third-party and absent; this is an independent implementation of the
+published PPO-clip + GAE algorithm (parity with SB3 is unpinned).
+
+MI355X-first choices:
+  * rollouts never leave the GPU: env step = one fused HIP launch, policy step = a handful of MFMA GEMMs, the rollout
+    buffer is a preallocated [T, N, ...] block in HBM (65 536 envs x 64 steps x 18 f32 = 302 MB -- trivial in 288 GB);
+  * sequences are whole rollouts per env, minibatches are env slices (BPTT over T with episode-start masking);
+  * gradients live in ONE flat fp32 buffer (parameters' .grad are views into it), so data parallelism is a single
+    `all_reduce` of ~7.3 MB per optimizer step on RCCL/xGMI -- latency-bound, hence one call instead of per-tensor
+    buckets; envs never communicate.
+"""
+import time
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from .policy import RateLSTMPolicy, RNNStates
+
+
+@dataclass
+class PPOConfig:
+    learning_rate: float = 3.0e-4
+    n_steps: int = 64            # per-env rollout length (reference: 2048 with 4 envs; here N is 10^4..10^5)
+    n_minibatches: int = 8       # env slices per epoch (reference expresses this as batch_size)
+    n_epochs: int = 10
+    gamma: float = 0.99
+    gae_lambda: float = 0.95
+    clip_range: float = 0.2
+    clip_range_vf: Optional[float] = None
+    ent_coef: float = 0.01
+    vf_coef: float = 0.5
+    max_grad_norm: float = 0.5
+    normalize_advantage: bool = True
+    bootstrap_timeouts: bool = False
+
+    @classmethod
+    def from_dict(cls, d: dict, **over):
+        keys = {"learning_rate", "n_steps", "n_epochs", "gamma", "gae_lambda", "clip_range", "clip_range_vf",
+                "ent_coef", "vf_coef", "max_grad_norm"}
+        kw = {k: v for k, v in d.items() if k in keys}
+        kw.update(over)
+        return cls(**kw)
+
+
+class FlatGrad:
+    """All parameter gradients as views of one contiguous buffer => one collective per optimizer step."""
+
+    def __init__(self, module: torch.nn.Module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        self.buf = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
+        off = 0
+        for p in self.params:
+            p.grad = self.buf[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.buf.zero_()
+
+    def all_reduce_mean(self):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)
+            self.buf.div_(dist.get_world_size())
+
+    def clip_norm_(self, max_norm: float):
+        norm = self.buf.norm()
+        self.buf.mul_(torch.clamp(max_norm / (norm + 1e-6), max=1.0))
+        return norm
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0):
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src)
+
+
+def compute_gae(rewards, values, episode_starts, last_values, last_dones, gamma, lam):
+    """rewards/values/episode_starts [T,N]; episode_starts[t] = 1 if env was reset before step t.  Returns adv, returns."""
+    T = rewards.shape[0]
+    adv = torch.zeros_like(rewards)
+    last = torch.zeros_like(last_values)
+    for t in range(T - 1, -1, -1):
+        if t == T - 1:
+            nonterminal, next_v = 1.0 - last_dones, last_values
+        else:
+            nonterminal, next_v = 1.0 - episode_starts[t + 1], values[t + 1]
+        delta = rewards[t] + gamma * next_v * nonterminal - values[t]
+        last = delta + gamma * lam * nonterminal * last
+        adv[t] = last
+    return adv, adv + values
+
+
+class RecurrentPPO:
+    def __init__(self, env, policy: Optional[RateLSTMPolicy] = None, config: Optional[PPOConfig] = None, seed: int = 0):
+        self.env, self.cfg = env, config or PPOConfig()
+        self.device = env.device
+        torch.manual_seed(seed)                          # identical initial weights on every rank
+        self.policy = (policy or RateLSTMPolicy()).to(self.device)
+        broadcast_parameters(self.policy)
+        self.flat = FlatGrad(self.policy)
+        self.opt = torch.optim.Adam(self.policy.parameters(), lr=self.cfg.learning_rate, eps=1e-5)
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        torch.manual_seed(seed + 7919 * (rank + 1))      # different exploration noise per rank
+        N, T = env.num_envs, self.cfg.n_steps
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.buf_obs = torch.zeros((T, N, 18), **f32)
+        self.buf_act = torch.zeros((T, N, 4), **f32)
+        self.buf_rew, self.buf_val, self.buf_logp, self.buf_start = (torch.zeros((T, N), **f32) for _ in range(4))
+        self.obs = env.reset().clone()
+        self.states = self.policy.initial_state(N, self.device)
+        self.episode_start = torch.ones(N, **f32)
+        self.num_timesteps = 0
+        self.ep_returns, self.ep_lengths = [], []
+        self.last_stats = {}
+
+    def set_env(self, env):
+        """Curriculum phases swap the env (train_rate.py:155-170); recurrent state and episode flags restart."""
+        assert env.num_envs == self.env.num_envs
+        self.env = env
+        self.obs = env.reset().clone()
+        self.states = self.policy.initial_state(env.num_envs, self.device)
+        self.episode_start = torch.ones(env.num_envs, dtype=torch.float32, device=self.device)
+
+    @torch.no_grad()
+    def collect_rollout(self):
+        env, pol, cfg = self.env, self.policy, self.cfg
+        self.rollout_states = self.states
+        ev_r, ev_l = [], []
+        for t in range(cfg.n_steps):
+            actions, values, logp, new_states = pol.step(self.obs, self.states, self.episode_start)
+            self.buf_obs[t], self.buf_act[t], self.buf_val[t], self.buf_logp[t], self.buf_start[t] = (
+                self.obs, actions, values, logp, self.episode_start)
+            obs, rew, term, trunc = env.step_device(actions)          # clip happens in-kernel (rate_env.py:225)
+            done = (term | trunc).float()
+            self.buf_rew[t] = rew
+            if cfg.bootstrap_timeouts:
+                # time-limit truncation is not failure: add gamma * V(s_T) (vec-env 'TimeLimit.truncated' handling).
+                # The post-step critic state belongs to the finished episode, so it can value the terminal observation.
+                ints, flts = env.episode_events()
+                if ints.shape[0]:
+                    tr = ints[:, 2] == 0
+                    if bool(tr.any()):
+                        ids = ints[tr, 0].long()
+                        v = pol.predict_values(flts[tr, 1:], new_states.index(ids), torch.zeros(ids.numel(), device=self.device))
+                        self.buf_rew[t, ids] += cfg.gamma * v
+            self.obs = obs.clone()
+            self.states, self.episode_start = new_states, done
+        self.num_timesteps += cfg.n_steps * env.num_envs
+        last_values = pol.predict_values(self.obs, self.states, self.episode_start)
+        self.adv, self.ret = compute_gae(self.buf_rew, self.buf_val, self.buf_start, last_values, self.episode_start,
+                                         cfg.gamma, cfg.gae_lambda)
+
+    def update(self):
+        cfg, pol = self.cfg, self.policy
+        N = self.env.num_envs
+        mb = max(1, N // cfg.n_minibatches)
+        stats = dict(policy_loss=0.0, value_loss=0.0, approx_kl=0.0, clip_frac=0.0, grad_norm=0.0, n=0)
+        for _ in range(cfg.n_epochs):
+            perm = torch.randperm(N, device=self.device)
+            for s in range(0, N - mb + 1, mb):
+                idx = perm[s:s + mb]
+                obs, act, starts = self.buf_obs[:, idx], self.buf_act[:, idx], self.buf_start[:, idx]
+                adv, ret, old_logp = self.adv[:, idx], self.ret[:, idx], self.buf_logp[:, idx]
+                values, logp, entropy = pol.evaluate_sequence(obs, act, starts, self.rollout_states.index(idx))
+                if cfg.normalize_advantage:
+                    adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+                ratio = torch.exp(logp - old_logp)
+                pl = -torch.min(adv * ratio, adv * torch.clamp(ratio, 1 - cfg.clip_range, 1 + cfg.clip_range)).mean()
+                if cfg.clip_range_vf is not None:
+                    old_v = self.buf_val[:, idx]
+                    values = old_v + torch.clamp(values - old_v, -cfg.clip_range_vf, cfg.clip_range_vf)
+                vl = torch.nn.functional.mse_loss(ret, values)
+                loss = pl + cfg.ent_coef * (-entropy) + cfg.vf_coef * vl
+                self.flat.zero()
+                loss.backward()
+                self.flat.all_reduce_mean()                    # THE collective: one flat ~7.3 MB all-reduce
+                gn = self.flat.clip_norm_(cfg.max_grad_norm)
+                self.opt.step()
+                with torch.no_grad():
+                    stats["policy_loss"] += pl.detach(); stats["value_loss"] += vl.detach()
+                    stats["approx_kl"] += ((ratio - 1) - (logp - old_logp)).mean()
+                    stats["clip_frac"] += ((ratio - 1).abs() > cfg.clip_range).float().mean()
+                    stats["grad_norm"] += gn; stats["n"] += 1
+        n = max(stats.pop("n"), 1)
+        self.last_stats = {k: float(v) / n for k, v in stats.items()}
+        self.last_stats["mean_reward_per_step"] = float(self.buf_rew.mean())
+        return self.last_stats
+
+    def learn(self, total_timesteps: int, log_interval: int = 1, callback=None):
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        target = self.num_timesteps + total_timesteps // world
+        it, t0 = 0, time.time()
+        while self.num_timesteps < target:
+            self.collect_rollout()
+            st = self.update()
+            it += 1
+            if callback is not None:
+                callback(self, st)
+            if log_interval and it % log_interval == 0 and (not dist.is_initialized() or dist.get_rank() == 0):
+                fps = self.cfg.n_steps * self.env.num_envs * world * it / max(time.time() - t0, 1e-9)
+                print(f"[ppo] iter {it} steps {self.num_timesteps * world} fps {fps:,.0f} "
+                      f"rew/step {st['mean_reward_per_step']:.3f} pl {st['policy_loss']:.4f} vl {st['value_loss']:.3f} "
+                      f"kl {st['approx_kl']:.4f} clip {st['clip_frac']:.3f}", flush=True)
+        return self
+
+    def save(self, path):
+        torch.save({"policy": self.policy.state_dict(), "optimizer": self.opt.state_dict(),
+                    "num_timesteps": self.num_timesteps, "config": self.cfg.__dict__}, path)
+
+    def load(self, path):
+        ck = torch.load(path, map_location=self.device, weights_only=True)
+        self.policy.load_state_dict(ck["policy"]); self.opt.load_state_dict(ck["optimizer"])
+        self.num_timesteps = ck["num_timesteps"]

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Train the learned rate controller: same CLI and config schema as the reference's learned_controllers/train_rate.py
+(:62-209) -- `--config`, `--no-lstm` -- with the curriculum loop of :150-180, on the device-resident env.
+
+    python -m hcrl_amd.train_rate --config <yaml>                       (1 GPU)
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m hcrl_amd.train_rate ...   (8 GPUs)
+"""
+import argparse
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .policy import RateLSTMPolicy
+from .ppo import PPOConfig, RecurrentPPO
+from .training_utils import (behavior_cloning_pretrain, collect_pid_demonstrations, create_vec_env, load_config,
+                             run_final_evaluation)
+
+DEFAULT_CONFIG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs", "training", "ppo_lstm.yaml")
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="Train learned rate controller")
+    ap.add_argument("--config", type=str, default=DEFAULT_CONFIG)
+    ap.add_argument("--no-lstm", action="store_true")
+    ap.add_argument("--bc-pretrain", type=int, default=0, help="behaviour-cloning epochs on fused-PID demonstrations")
+    ap.add_argument("--timesteps-scale", type=float, default=1.0)
+    ap.add_argument("--precision", default="mixed")
+    ap.add_argument("--bf16", action="store_true", help="run the policy GEMMs in bf16 (fp32 accumulate)")
+    args = ap.parse_args(argv)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    rank = dist.get_rank() if world > 1 else 0
+
+    config = load_config(args.config)
+    seed = config.get("seed", 42)
+    np.random.seed(seed)
+    n_envs = config["training"]["n_envs"]
+    use_lstm = not (args.no_lstm or not config["lstm"]["enabled"])
+    policy = RateLSTMPolicy(features_dim=config["lstm"]["features_dim"], lstm_hidden_size=config["lstm"]["lstm_hidden_size"],
+                            n_lstm_layers=config["lstm"]["n_lstm_layers"], use_lstm=use_lstm,
+                            mlp_net_arch=tuple(config["mlp"]["net_arch"]),
+                            compute_dtype=torch.bfloat16 if args.bf16 else None)
+    env = create_vec_env(config, n_envs=n_envs, seed=seed + rank * n_envs, precision=args.precision)
+    model = RecurrentPPO(env, policy, PPOConfig.from_dict(config["ppo"]), seed=seed)
+
+    if args.bc_pretrain and rank == 0:
+        obs, acts = collect_pid_demonstrations(n_episodes=2048, difficulty="medium", seed=seed)
+        print("BC losses:", behavior_cloning_pretrain(model, obs, acts, epochs=args.bc_pretrain))
+    if world > 1:
+        from .ppo import broadcast_parameters
+        broadcast_parameters(model.policy)
+
+    if config["curriculum"]["enabled"]:
+        for phase in config["curriculum"]["phases"]:
+            config["environment"]["difficulty"] = phase["difficulty"]
+            config["environment"]["command_type"] = phase["command_type"]
+            env = create_vec_env(config, n_envs=n_envs, seed=seed + rank * n_envs, precision=args.precision)
+            model.set_env(env)
+            if rank == 0:
+                print(f"=== phase {phase['name']}: {phase['difficulty']}/{phase['command_type']} {phase['timesteps']} steps")
+            model.learn(int(phase["timesteps"] * args.timesteps_scale), log_interval=config["training"]["log_interval"])
+    else:
+        model.learn(int(config["training"]["total_timesteps"] * args.timesteps_scale),
+                    log_interval=config["training"]["log_interval"])
+
+    if rank == 0:
+        os.makedirs(config["paths"]["model_save_dir"], exist_ok=True)
+        model.save(os.path.join(config["paths"]["model_save_dir"], "final_model.pt"))
+        print("final evaluation:", {k: v for k, v in run_final_evaluation(model).items() if k.startswith("mean")})
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

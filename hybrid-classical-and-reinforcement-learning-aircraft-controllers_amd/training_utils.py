@@ -1,0 +1,103 @@
+"""Trainer glue with the reference's names and signatures (learned_controllers/utils/training_utils.py:23-249,
+learned_controllers/utils/pid_demonstrations.py:13-110), over the device-resident env.
+"""
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+import yaml
+
+from .rate_env import GpuRateVecEnv
+
+
+def load_config(config_path: str) -> dict:
+    """training_utils.py:144-155 -- plain YAML -> dict; the reference's config files load unchanged."""
+    with open(config_path, "r") as f:
+        return yaml.safe_load(f)
+
+
+def create_vec_env(config: dict, n_envs: int = 4, seed: Optional[int] = None, **kw) -> GpuRateVecEnv:
+    """training_utils.py:49-69: same arguments; returns ONE device-resident vec-env instead of n_envs subprocesses.
+    Env `i` is seeded `seed + i` like `make_env(config, rank=i, seed)` (:41)."""
+    e = config["environment"]
+    return GpuRateVecEnv(n_envs, e["difficulty"], e["episode_length"], e["dt"], e["command_type"], seed=seed, **kw)
+
+
+def collect_pid_demonstrations(n_episodes: int = 100, difficulty: str = "medium", save_path: Optional[str] = None,
+                               seed: int = 42, n_envs: Optional[int] = None, precision: str = "mixed",
+                               sampling: str = "device") -> Tuple[np.ndarray, np.ndarray]:
+    """pid_demonstrations.py:13-110: roll the rate PID (throttle 0.6, dt 0.02) in the env and record (obs_t, action_t).
+
+    Here `n_envs` envs fly one episode each in parallel with the PID fused into the env-step kernel.  Unlike the
+    reference -- which appends its re-used observation buffer un-copied and so stores one unique row --
+    each pair holds the observation the action was computed from.
+    """
+    n = n_envs or n_episodes
+    env = GpuRateVecEnv(n, difficulty, 10.0, 0.02, "step", seed=seed, precision=precision, sampling=sampling)
+    obs = env.reset().clone()
+    alive = torch.ones(n, dtype=torch.bool, device=env.device)
+    obs_l, act_l = [], []
+    for _ in range(int(10.0 / 0.02)):
+        _, _, term, trunc = env.step_device(None, auto_reset=False)
+        obs_l.append(obs[alive].clone())
+        act_l.append(env.actions_taken[alive].clone())
+        alive &= ~(term | trunc).bool()
+        obs = env.obs.clone()
+        if not bool(alive.any()):
+            break
+    observations = torch.cat(obs_l).cpu().numpy().astype(np.float32)
+    actions = torch.cat(act_l).cpu().numpy().astype(np.float32)
+    if save_path:
+        os.makedirs(os.path.dirname(os.path.abspath(save_path)), exist_ok=True)
+        np.savez_compressed(save_path, observations=observations, actions=actions)   # data-only file, no pickle
+    return observations, actions
+
+
+def behavior_cloning_pretrain(model, observations, actions, epochs=10, batch_size=256, lr=1e-3):
+    """training_utils.py:158-213: MSE(mean_action, expert) with Adam on the actor trunk + action head.
+    `model` is a RecurrentPPO / anything with `.policy`; recurrent policies are cloned from zero state."""
+    policy = model.policy
+    dev = next(policy.parameters()).device
+    obs_t = torch.as_tensor(observations, dtype=torch.float32, device=dev)
+    act_t = torch.as_tensor(actions, dtype=torch.float32, device=dev)
+    params = [p for n, p in policy.named_parameters() if not n.startswith(("vf_net", "value_net", "lstm_critic", "log_std"))]
+    opt = torch.optim.Adam(params, lr=lr)
+    losses = []
+    for _ in range(epochs):
+        perm = torch.randperm(obs_t.shape[0], device=dev)
+        total, nb = 0.0, 0
+        for s in range(0, obs_t.shape[0], batch_size):
+            idx = perm[s:s + batch_size]
+            st = policy.initial_state(idx.numel(), dev)
+            lat_pi, _, _ = policy._core(obs_t[idx], st)
+            loss = torch.nn.functional.mse_loss(policy.action_net(lat_pi), act_t[idx])
+            opt.zero_grad(set_to_none=False)
+            loss.backward()
+            opt.step()
+            total += float(loss.detach()); nb += 1
+        losses.append(total / max(nb, 1))
+    return losses
+
+
+@torch.no_grad()
+def run_final_evaluation(model, difficulty="hard", n_episodes=10, dt=0.02, seed=0):
+    """training_utils.py:216-249: deterministic policy, one episode per env, mean length and return."""
+    env = GpuRateVecEnv(n_episodes, difficulty, 10.0, dt, "step", seed=seed, precision="mixed", sampling="device")
+    obs = env.reset().clone()
+    pol = model.policy
+    st = pol.initial_state(n_episodes, env.device)
+    start = torch.ones(n_episodes, device=env.device)
+    alive = torch.ones(n_episodes, dtype=torch.bool, device=env.device)
+    ret = torch.zeros(n_episodes, device=env.device); length = torch.zeros(n_episodes, device=env.device)
+    for _ in range(int(10.0 / dt)):
+        a, _, _, st = pol.step(obs, st, start, deterministic=True)
+        start = torch.zeros_like(start)
+        obs, rew, term, trunc = env.step_device(a, auto_reset=False)
+        obs = obs.clone()
+        ret += rew * alive; length += alive.float()
+        alive &= ~(term | trunc).bool()
+        if not bool(alive.any()):
+            break
+    return {"mean_length": float(length.mean()), "mean_reward": float(ret.mean()), "lengths": length.cpu().numpy(),
+            "rewards": ret.cpu().numpy()}
