@@ -1,0 +1,118 @@
+"""GPU: the single-object drop-in surfaces (AircraftInterface backend, gym-style RateControlEnv, the
+`aircraft_controls_bindings` module) behave like the reference's, checked with the reference's own known answers
+(tests/test_pid_bindings.py, tests/test_simulation.py) and the reference-generated fixtures."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO, load_golden, rel_err, STATE_ANGLE_COLS
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(REPO, "compat"))
+
+
+@pytest.fixture(scope="module")
+def acb():
+    import aircraft_controls_bindings
+    return aircraft_controls_bindings
+
+
+def test_acb_known_answers(acb):
+    assert acb.__version__ == "1.1.0"
+    c = acb.PIDConfig()
+    assert (c.output_min, c.output_max, c.integral_min, c.integral_max) == (-1.0, 1.0, -10.0, 10.0)     # :45-53
+    c.gains = acb.PIDGains(2.0, 0.0, 0.0)
+    pid = acb.PIDController(c)
+    assert pid.compute(10.0, 0.0, 0.01) == 1.0 and pid.compute(-10.0, 0.0, 0.01) == -1.0               # :89-102
+    c = acb.PIDConfig(); c.gains = acb.PIDGains(0.0, 1.0, 0.0); c.output_min, c.output_max = -100.0, 100.0
+    pid = acb.PIDController(c)
+    for _ in range(10):
+        pid.compute(1.0, 0.0, 0.1)
+    assert abs(pid.get_integral() - 1.0) < 1e-5                                                        # :104-123
+    pid.reset()
+    assert pid.get_integral() == 0.0 and pid.get_error() == 0.0 and pid.get_output() == 0.0            # :125-146
+    c.integral_min, c.integral_max = -5.0, 5.0
+    pid = acb.PIDController(c)
+    for _ in range(100):
+        pid.compute(10.0, 0.0, 0.1)
+    assert pid.get_integral() == 5.0                                                                   # :175-190
+    c = acb.PIDConfig(); c.gains = acb.PIDGains(0.0, 0.0, 1.0); c.output_min, c.output_max = -100.0, 100.0
+    c.derivative_filter_alpha = 1.0
+    pid = acb.PIDController(c)
+    pid.compute(0.0, 0.0, 0.1)
+    assert abs(pid.compute(5.0, 0.0, 0.1) - 50.0) < 1e-3                                               # :192-209
+    m = acb.MultiAxisPIDController()
+    m.set_gains(7, acb.PIDGains(1, 1, 1))                       # invalid axis: no-op
+    assert m.get_gains(7).kp == 0.0 and m.get_gains(0).kp == 0.0
+    m.set_gains(1, acb.PIDGains(0.5, 0, 0))
+    out = m.compute(acb.Vector3(1, 1, 1), acb.Vector3(0, 0, 0), 0.01)
+    assert (out.roll, out.pitch, out.yaw) == (0.0, 0.5, 0.0) and m.get_error().y == 1.0
+
+
+def test_backend_contract():
+    from hcrl_amd.backend import AircraftInterface, SimulationAircraftBackend
+    from hcrl_amd.flight_types import ControlSurfaces
+    b = SimulationAircraftBackend({"aircraft_type": "cessna"})
+    assert isinstance(b, AircraftInterface) and b.get_backend_type() == "simulation" and b.supports_reset()
+    assert b.get_info()["aircraft_mass"] == 15.0 and b.get_info()["physics_engine"] == "simplified_6dof"
+    s = b.reset()
+    assert abs(s.altitude - 100.0) < 1e-9 and abs(s.airspeed - 20.0) < 1e-9                            # test_simulation.py:46-62
+    b.set_controls(ControlSurfaces(elevator=0.0, aileron=0.0, rudder=0.0, throttle=0.0))
+    s2 = b.step(0.1)
+    assert abs(s2.time - 0.1) < 1e-9 and s2.altitude < 100.0                                           # :113,266-276
+    with pytest.raises(ValueError):
+        b.step(1e-7)                       # one sub-step of 1e-7 s <= min_timestep (simplified_6dof.py:241)
+
+
+def test_cfg1_harness_through_dropin_objects(acb):
+    """examples/01_hello_controls.py loop over the drop-in objects: acb rate PIDs + SimulationAircraftBackend."""
+    from hcrl_amd.backend import SimulationAircraftBackend
+    from hcrl_amd.flight_types import AircraftState, ControlSurfaces, ControllerConfig
+    g = load_golden("cfg1_rate_pid.npz")
+    cfg = ControllerConfig()
+
+    def mk(gains):
+        c = acb.PIDConfig()
+        c.gains = acb.PIDGains(gains.kp, gains.ki, gains.kd)
+        c.integral_min, c.integral_max = -gains.i_limit, gains.i_limit
+        return c
+    rate = acb.MultiAxisPIDController(mk(cfg.roll_rate_gains), mk(cfg.pitch_rate_gains), mk(cfg.yaw_gains))
+    b = SimulationAircraftBackend({"aircraft_type": "rc_plane"})
+    state = b.reset(AircraftState.from_vector(g["x0"]))
+    worst = 0.0
+    for i in range(200):
+        lim = np.radians([cfg.max_roll_rate, cfg.max_pitch_rate, cfg.max_yaw_rate])
+        sp = np.clip(g["cmd"][:3], -lim, lim)
+        o = rate.compute(acb.Vector3(*sp), acb.Vector3(state.p, state.q, state.r), 0.01)
+        surf = ControlSurfaces(aileron=float(np.clip(o.roll, -1, 1)), elevator=float(np.clip(-o.pitch, -1, 1)),
+                               rudder=float(np.clip(-o.yaw, -1, 1)), throttle=float(np.clip(g["cmd"][3], 0, 1)))
+        assert abs(surf.aileron - g["surfaces"][i, 1]) < 1e-5
+        b.set_controls(surf)
+        state = b.step(0.01)
+        worst = max(worst, rel_err(state.to_vector(), g["traj"][i], STATE_ANGLE_COLS).max())
+    assert worst < 1e-7, worst
+
+
+def test_gym_env_reproduces_survey_episode():
+    from hcrl_amd.gym_env import RateControlEnv
+    g = load_golden("env_easy_step_seed42_const.npz")
+    env = RateControlEnv(difficulty="easy", episode_length=10, dt=0.02, command_type="step", rng_seed=42)
+    obs, info = env.reset(seed=42)
+    assert obs.dtype == np.float32 and obs.shape == (18,) and env.observation_space.shape == (18,)
+    assert np.allclose(env.rate_command, [-0.90996233, -0.79713236, -0.34282152], atol=1e-8)
+    assert np.allclose(obs[9:14], [20.6181, 192.6071, 0.1214717, 0.05165746, 0.980294], rtol=1e-6)
+    assert set(info) >= {"time", "step", "position", "rate_command", "rate_error", "airspeed", "altitude", "is_settled"}
+    total, k = 0.0, 0
+    while True:
+        obs, r, term, trunc, info = env.step(np.array([0.1, 0.0, 0.0, 0.6], dtype=np.float32))
+        total += r
+        k += 1
+        if term or trunc:
+            break
+    assert k == 150 and term and not trunc and abs(total + 15.188049) < 1e-5
+    st = env.sim.get_state()
+    assert abs(st.altitude - info["altitude"]) < 1e-9
+    obs2, _ = env.reset()                                         # next episode continues the sampler streams
+    assert rel_err(obs2, obs).max() > 1e-3
