@@ -31,6 +31,9 @@ SIGNATURES = {
     "fdyn_rate_env_reset_f32": (_i, _ENV_RESET),
     "fdyn_rate_env_step_f64": (_i, _ENV_STEP), "fdyn_rate_env_step_mixed": (_i, _ENV_STEP),
     "fdyn_rate_env_step_f32": (_i, _ENV_STEP),
+    "fdyn_lstm_cell_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i64, _i, _p]),
+    "fdyn_lstm_cell_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i64, _i, _p]),
+    "fdyn_gae": (_i, [_p, _p, _p, _p, _p, _f, _f, _i, _i64, _p, _p, _p]),
 }
 
 _lib = None

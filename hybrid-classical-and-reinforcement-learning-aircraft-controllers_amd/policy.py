@@ -24,6 +24,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .fused import lstm_cell
+
 OBS_DIM, ACT_DIM = 18, 4
 
 
@@ -39,26 +41,21 @@ class RNNStates(NamedTuple):
     def masked(self, keep):
         """keep = 1 - episode_start, [B] -> zero the state of envs that start a new episode."""
         k = keep.unsqueeze(-1)
-        return RNNStates(*(t * k for t in self))
+        return RNNStates(*(t * k.to(t.dtype) for t in self))
 
     def index(self, idx):
         return RNNStates(*(t[idx] for t in self))
 
 
 def _lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh):
-    """One LSTM step as ONE fused GEMM over the concatenated [x, h] (K = in + H) -- PyTorch gate order i, f, g, o."""
+    """One LSTM step: ONE GEMM over the concatenated [x, h] (K = in + H, MFMA via hipBLASLt; PyTorch gate order
+    i, f, g, o) followed by ONE fused point-wise launch (fused.lstm_cell)."""
     gates = F.linear(torch.cat([x, h.to(x.dtype)], dim=-1), torch.cat([w_ih, w_hh], dim=1), b_ih + b_hh)
-    i, f, g, o = gates.float().chunk(4, dim=-1)
-    c_new = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
-    h_new = torch.sigmoid(o) * torch.tanh(c_new)
-    return h_new, c_new
+    return lstm_cell(gates, c)
 
 
 def _lstm_zero_state_layer(x, w_ih, b_ih, b_hh):
-    gates = F.linear(x, w_ih, b_ih + b_hh)
-    i, _f, g, o = gates.float().chunk(4, dim=-1)
-    c = torch.sigmoid(i) * torch.tanh(g)
-    return torch.sigmoid(o) * torch.tanh(c)
+    return lstm_cell(F.linear(x, w_ih, b_ih + b_hh), None)[0]
 
 
 class LSTMFeaturesExtractor(nn.Module):
@@ -130,7 +127,7 @@ class RateLSTMPolicy(nn.Module):
         la, lc = self.lstm_actor, self.lstm_critic
         pi_h, pi_c = _lstm_cell(feats, states.pi_h, states.pi_c, la.weight_ih_l0, la.weight_hh_l0, la.bias_ih_l0, la.bias_hh_l0)
         vf_h, vf_c = _lstm_cell(feats, states.vf_h, states.vf_c, lc.weight_ih_l0, lc.weight_hh_l0, lc.bias_ih_l0, lc.bias_hh_l0)
-        return self.pi_net(pi_h.to(feats.dtype)), self.vf_net(vf_h.to(feats.dtype)), RNNStates(pi_h, pi_c, vf_h, vf_c)
+        return self.pi_net(pi_h), self.vf_net(vf_h), RNNStates(pi_h, pi_c, vf_h, vf_c)
 
     def step(self, obs, states: RNNStates, episode_start, deterministic: bool = False):
         """obs [B,18], episode_start [B] (1 where the env was just reset) -> actions, values, log_probs, new states."""
@@ -169,18 +166,13 @@ class RateLSTMPolicy(nn.Module):
             pi_h, pi_c, vf_h, vf_c = states
             for t in range(T):
                 keep = (1.0 - episode_starts[t].float()).unsqueeze(-1)
-                pi_h, pi_c, vf_h, vf_c = pi_h * keep, pi_c * keep, vf_h * keep, vf_c * keep
+                kh = keep.to(pi_h.dtype)
+                pi_h, pi_c, vf_h, vf_c = pi_h * kh, pi_c * keep, vf_h * kh, vf_c * keep
                 x = feats[t]
-                ga = F.linear(torch.cat([x, pi_h.to(x.dtype)], -1), wa, ba).float()
-                gc = F.linear(torch.cat([x, vf_h.to(x.dtype)], -1), wc, bc).float()
-                i, f, g, o = ga.chunk(4, -1)
-                pi_c = torch.sigmoid(f) * pi_c + torch.sigmoid(i) * torch.tanh(g)
-                pi_h = torch.sigmoid(o) * torch.tanh(pi_c)
-                i, f, g, o = gc.chunk(4, -1)
-                vf_c = torch.sigmoid(f) * vf_c + torch.sigmoid(i) * torch.tanh(g)
-                vf_h = torch.sigmoid(o) * torch.tanh(vf_c)
+                pi_h, pi_c = lstm_cell(F.linear(torch.cat([x, pi_h.to(x.dtype)], -1), wa, ba), pi_c)
+                vf_h, vf_c = lstm_cell(F.linear(torch.cat([x, vf_h.to(x.dtype)], -1), wc, bc), vf_c)
                 pi_hs.append(pi_h); vf_hs.append(vf_h)
-            pi_seq, vf_seq = torch.stack(pi_hs).to(feats.dtype), torch.stack(vf_hs).to(feats.dtype)
+            pi_seq, vf_seq = torch.stack(pi_hs), torch.stack(vf_hs)
             mean = self.action_net(self.pi_net(pi_seq)).float()
             values = self.value_net(self.vf_net(vf_seq)).float().squeeze(-1)
         return values, self._log_prob(actions, mean), self.entropy()

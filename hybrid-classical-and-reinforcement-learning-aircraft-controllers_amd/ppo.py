@@ -83,6 +83,9 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0):
 
 def compute_gae(rewards, values, episode_starts, last_values, last_dones, gamma, lam):
     """rewards/values/episode_starts [T,N]; episode_starts[t] = 1 if env was reset before step t.  Returns adv, returns."""
+    if rewards.is_cuda:
+        from .fused import gae
+        return gae(rewards, values, episode_starts, last_values, last_dones, gamma, lam)
     T = rewards.shape[0]
     adv = torch.zeros_like(rewards)
     last = torch.zeros_like(last_values)

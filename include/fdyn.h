@@ -116,6 +116,22 @@ FDYN_DECLARE_ENV(f64, double)
 FDYN_DECLARE_ENV(mixed, double)
 FDYN_DECLARE_ENV(f32, float)
 
+/* ---- policy-side fused kernels (csrc/policy_kernels.hip) ------------------------------------------------------------
+ * LSTM cell point-wise update from pre-activation gates [B][4H] (PyTorch order i,f,g,o; bias already added by the
+ * GEMM): replaces the ~40 element-wise launches torch needs per cell (nn.LSTM arithmetic used by
+ * learned_controllers/networks/lstm_policy.py:49-61 and sb3_contrib's actor/critic LSTMs).
+ * gates_bf16: 1 = bf16 storage for gates/h_lp/act/dh/dgates, 0 = fp32.  c_prev NULL = zero state.  H % 8 == 0.
+ * fwd: h_f32 [B][H] and/or h_lp [B][H] (either may be NULL), c_out [B][H] fp32, act_out [B][4H] activated gates or NULL.
+ * bwd: from act, c_prev, c_new, dh (+ dc_next or NULL) -> dgates [B][4H], dc_prev [B][H] (or NULL).                   */
+int fdyn_lstm_cell_fwd(const void* gates, int gates_bf16, const float* c_prev, float* h_f32, void* h_lp, float* c_out,
+                       void* act_out, int64_t B, int H, void* stream);
+int fdyn_lstm_cell_bwd(const void* act, int bf16, const float* c_prev, const float* c_new, const void* dh,
+                       const float* dc_next, void* dgates, float* dc_prev, int64_t B, int H, void* stream);
+/* GAE(lambda) over a [T][N] rollout (one lane per env): adv, ret [T][N].  episode_starts[t][n] = 1 if env n was reset
+ * before step t; last_values / last_dones [N] describe the state after the final step.                              */
+int fdyn_gae(const float* rewards, const float* values, const float* episode_starts, const float* last_values,
+             const float* last_dones, float gamma, float lam, int T, int64_t N, float* adv, float* ret, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,7 +4,7 @@ for d in bf16 fp32; do
  timeout -k 10 300 python bench.py --workload rollout --policy-dtype $d --steps 100 --warmup 10 --no-cpu-baseline 2>gpurun_out/rollout_$d.err | tail -1 > gpurun_out/bench_rollout_$d.json
  timeout -k 10 300 python bench.py --workload train --policy-dtype $d --steps 3 --warmup 1 --no-cpu-baseline 2>gpurun_out/train_$d.err | tail -1 > gpurun_out/bench_train_$d.json
 done
-tail -3 gpurun_out/rollout_bf16.err gpurun_out/train_bf16.err
+tail -n 3 gpurun_out/rollout_bf16.err gpurun_out/train_bf16.err
 python - <<'PY'
 import json,glob
 for f in sorted(glob.glob('gpurun_out/bench_rollout_*.json')+glob.glob('gpurun_out/bench_train_*.json')):
