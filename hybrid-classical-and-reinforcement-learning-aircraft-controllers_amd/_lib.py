@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libfdyn_hip.so")
+LIB_PATH = os.environ.get("FDYN_LIB", os.path.join(_HERE, "csrc", "libfdyn_hip.so"))   # FDYN_LIB: A/B experiment builds
 
 FDYN_OK, FDYN_ERR_BAD_DT, FDYN_ERR_BAD_TYPES, FDYN_ERR_BAD_SIZE, FDYN_ERR_NULL = 0, -1, -2, -3, -4
 
@@ -23,6 +23,7 @@ SIGNATURES = {
     "fdyn_abi_version": (_i, []),
     "fdyn_num_substeps": (_i, [_d, _d]),
     "fdyn_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
+    "fdyn_set_lanes_per_wave": (_i, [_i]),
     "fdyn_sixdof_step_f64": (_i, _SIXDOF), "fdyn_sixdof_step_mixed": (_i, _SIXDOF), "fdyn_sixdof_step_f32": (_i, _SIXDOF),
     "fdyn_derived_f64": (_i, [_p, _i64, _p, _p]), "fdyn_derived_f32": (_i, [_p, _i64, _p, _p]),
     "fdyn_pid_compute_batch": (_i, [_p, _i, _p, _p, _p, _f, _p, _i64, _p]),

@@ -42,6 +42,7 @@ template <> struct M<double> {
 namespace fast {
 FD_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }          // v_rcp_f32, 1 ulp
 FD_DEV float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }        // v_sqrt_f32, 1 ulp
+FD_DEV float rsq(float x) { return __builtin_amdgcn_rsqf(x); }          // v_rsq_f32, 1 ulp
 FD_DEV void sincos(float x, float& s, float& c)
 {
     const float k = __builtin_rintf(x * 0.63661977236758134f);          // nearest multiple of pi/2
@@ -60,6 +61,15 @@ FD_DEV void sincos(float x, float& s, float& c)
     const float ss = swap ? cr : sr, cc = swap ? sr : cr;
     s = (q & 2) ? -ss : ss;
     c = ((q + 1) & 2) ? -cc : cc;
+}
+// v_sin_f32 / v_cos_f32 (argument in revolutions): 3 instructions instead of ~26, but ~4x the drift of the software
+// version (measured: the mixed variant leaves the 1e-4 gate, 1.8e-4 on the dt = 10 ms fixture).  Used only by the pure
+// fp32 throughput variant, which is outside the gate anyway.
+FD_DEV void sincos_hw(float x, float& s, float& c)
+{
+    const float rev = x * 0.15915494309189535f;
+    s = __builtin_amdgcn_sinf(rev);
+    c = __builtin_amdgcn_cosf(rev);
 }
 FD_DEV float atan_pos(float a)
 {   // atan for a >= 0 (Cephes atanf: two range reductions + degree-4 polynomial in a^2), branch-free
@@ -123,6 +133,12 @@ FD_DEV float fdiv(float a, float b) { return a * fast::rcp(b); }
 template <typename T> FD_DEV T clipv(T x, T lo, T hi) { return x < lo ? lo : (x > hi ? hi : x); }   // np.clip, NaN stays
 template <typename T> FD_DEV T pymax(T a, T b) { return b > a ? b : a; }                            // max(a, b)
 template <typename T> FD_DEV T pymin(T a, T b) { return b < a ? b : a; }                            // min(a, b)
+// single-instruction forms for the fp32 evaluation path (v_med3_f32 / v_max_f32).  They do not propagate NaN the way
+// np.clip does, which is why dynamics<float> tests finiteness BEFORE its derivative clamps.
+FD_DEV float clipf(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+FD_DEV double clipf(double x, double lo, double hi) { return clipv(x, lo, hi); }
+FD_DEV float maxf(float a, float b) { return __builtin_fmaxf(a, b); }
+FD_DEV double maxf(double a, double b) { return pymax(a, b); }
 template <typename T> FD_DEV T signv(T x) { return x > T(0) ? T(1) : (x < T(0) ? T(-1) : x); }      // np.sign (0->0, NaN->NaN)
 
 #define FD_PI 3.14159265358979323846
@@ -144,7 +160,7 @@ template <typename T> struct Params {
     T damp_roll, damp_pitch, damp_yaw, max_thrust, half_rho, g;
     T min_airspeed, min_u, max_de, max_da, max_dr, thrust_zero_v;
     T max_alpha, max_pitch, max_acc, max_ang_acc;
-    T inv_ixx, inv_iyy, inv_izz;
+    T inv_ixx, inv_iyy, inv_izz, sin_max_alpha, cos_max_alpha;
 
     // `blk` points at one FD_NP-word block staged in LDS (stored as double; narrowed here once per launch)
     FD_DEV void load(const double* blk)
@@ -165,6 +181,7 @@ template <typename T> struct Params {
         max_alpha = T(blk[FD_P_MAX_ALPHA_RAD]); max_pitch = T(blk[FD_P_MAX_PITCH_RAD]);
         max_acc = T(blk[FD_P_MAX_ACCELERATION]); max_ang_acc = T(blk[FD_P_MAX_ANGULAR_ACCELERATION]);
         inv_ixx = T(1) / ixx; inv_iyy = T(1) / iyy; inv_izz = T(1) / izz;     // used by the fp32 variants only
+        sin_max_alpha = T(::sin(blk[FD_P_MAX_ALPHA_RAD])); cos_max_alpha = T(::cos(blk[FD_P_MAX_ALPHA_RAD]));
     }
 };
 
@@ -191,26 +208,44 @@ template <typename T> struct Controls {
 };
 
 // ----- one evaluation of the equations of motion: simplified_6dof.py:333-503 ----------------------------
-template <typename T>
+template <typename T, bool HW_TRIG = false>
 FD_DEV void dynamics(const Params<T>& P, const Controls<T>& C, const T (&x)[FD_NX], T (&xd)[FD_NX])
 {
     const T u = x[3], v = x[4], w = x[5], theta = x[7];
     const T p = x[9], q = x[10], r = x[11];
     T sin_phi, cos_phi, sin_theta, cos_theta, sin_psi, cos_psi;
-    M<T>::sincos(x[6], sin_phi, cos_phi);
-    M<T>::sincos(theta, sin_theta, cos_theta);
-    M<T>::sincos(x[8], sin_psi, cos_psi);
+    if constexpr (HW_TRIG) {
+        fast::sincos_hw(x[6], sin_phi, cos_phi);
+        fast::sincos_hw(theta, sin_theta, cos_theta);
+        fast::sincos_hw(x[8], sin_psi, cos_psi);
+    } else {
+        M<T>::sincos(x[6], sin_phi, cos_phi);
+        M<T>::sincos(theta, sin_theta, cos_theta);
+        M<T>::sincos(x[8], sin_psi, cos_psi);
+    }
 
     const T airspeed = M<T>::sqrt(u * u + v * v + w * w);                               // :363
-    const T safe_airspeed = pymax(airspeed, P.min_airspeed);                            // :364
+    const T safe_airspeed = maxf(airspeed, P.min_airspeed);                             // :364
     const T au = M<T>::abs(u);
-    const T u_safe = au > T(1e-6) ? pymax(au, P.min_u) * signv(u) : P.min_u;            // :368
+    T u_safe;                                                                           // :368
+    if constexpr (sizeof(T) == 8) u_safe = au > T(1e-6) ? pymax(au, P.min_u) * signv(u) : P.min_u;
+    else u_safe = au > T(1e-6) ? __builtin_copysignf(__builtin_fmaxf(au, P.min_u), u) : P.min_u;
     T alpha = M<T>::atan2(w, u_safe);
-    alpha = clipv(alpha, -P.max_alpha, P.max_alpha);                                    // :370
     T sin_alpha, cos_alpha;
-    M<T>::sincos(alpha, sin_alpha, cos_alpha);
+    if constexpr (sizeof(T) == 8) {
+        alpha = clipv(alpha, -P.max_alpha, P.max_alpha);                                // :370
+        M<T>::sincos(alpha, sin_alpha, cos_alpha);
+    } else {
+        // sin/cos of the UNCLIPPED alpha are w/h and u_safe/h (h = hypot): one v_rsq instead of a sincos; the clipped
+        // cases take the pre-computed sin/cos of +-max_alpha
+        const T inv_h = fast::rsq(u_safe * u_safe + w * w);
+        const bool hi = alpha > P.max_alpha, lo = alpha < -P.max_alpha;
+        sin_alpha = hi ? P.sin_max_alpha : (lo ? -P.sin_max_alpha : w * inv_h);
+        cos_alpha = (hi || lo) ? P.cos_max_alpha : u_safe * inv_h;
+        alpha = clipf(alpha, -P.max_alpha, P.max_alpha);
+    }
     const T inv_V = fdiv(T(1), safe_airspeed);                                          // fp32 only: one v_rcp, reused
-    const T beta = M<T>::asin(clipv(sizeof(T) == 8 ? v / safe_airspeed : v * inv_V, T(-1), T(1)));                   // :376
+    const T beta = M<T>::asin(clipf(sizeof(T) == 8 ? v / safe_airspeed : v * inv_V, T(-1), T(1)));                   // :376
     const T q_dyn = P.half_rho * (airspeed * airspeed);                                 // :379 (unclamped V)
 
     const T cl = P.cl_0 + P.cl_alpha * alpha + P.cl_de * C.de_rad;                      // :384-390
@@ -221,7 +256,7 @@ FD_DEV void dynamics(const Params<T>& P, const Controls<T>& C, const T (&x)[FD_N
     const T fx_aero = -drag * cos_alpha + lift * sin_alpha;                             // :397-399
     const T fz_aero = -drag * sin_alpha - lift * cos_alpha;
 
-    const T thrust_factor = pymax(T(0), T(1) - fdiv(airspeed, P.thrust_zero_v));             // :403
+    const T thrust_factor = maxf(T(0), T(1) - fdiv(airspeed, P.thrust_zero_v));             // :403
     const T thrust = P.max_thrust * C.throttle * thrust_factor;
 
     const T fx = fx_aero + thrust + (-P.g * sin_theta) * P.mass;                        // :409-411
@@ -249,7 +284,7 @@ FD_DEV void dynamics(const Params<T>& P, const Controls<T>& C, const T (&x)[FD_N
     xd[4] = fy * P.inv_mass - r * u + p * w;
     xd[5] = fz * P.inv_mass - p * v + q * u;
 
-    const T theta_safe = clipv(theta, -P.max_pitch, P.max_pitch);                       // :463-471
+    const T theta_safe = clipf(theta, -P.max_pitch, P.max_pitch);                       // :463-471
     T cos_ts, tan_ts;
     if constexpr (sizeof(T) == 8) {
         cos_ts = (theta_safe == theta) ? cos_theta : M<T>::cos(theta_safe);
@@ -276,18 +311,38 @@ FD_DEV void dynamics(const Params<T>& P, const Controls<T>& C, const T (&x)[FD_N
         xd[11] = (n_moment - (P.iyy - P.ixx) * p * q) * P.inv_izz;
     }
 
+    if constexpr (sizeof(T) == 8) {
 #pragma unroll
-    for (int i = 9; i < 12; ++i) xd[i] = clipv(xd[i], -P.max_ang_acc, P.max_ang_acc);  // :485-490
+        for (int i = 9; i < 12; ++i) xd[i] = clipv(xd[i], -P.max_ang_acc, P.max_ang_acc);  // :485-490
 #pragma unroll
-    for (int i = 3; i < 6; ++i) xd[i] = clipv(xd[i], -P.max_acc, P.max_acc);
-    // :496-501 non-finite derivatives -> 0.  Every derivative is bounded (clamped or O(100)), so their sum is finite
-    // iff each one is: one class test on the sum guards a rare, wave-uniformly-skipped fix-up branch.
-    T acc = xd[0];
+        for (int i = 3; i < 6; ++i) xd[i] = clipv(xd[i], -P.max_acc, P.max_acc);
+        // :496-501 non-finite derivatives -> 0.  Every derivative is bounded (clamped or O(100)), so their sum is
+        // finite iff each one is: one class test on the sum guards a rare, wave-uniformly-skipped fix-up branch.
+        T acc = xd[0];
 #pragma unroll
-    for (int i = 1; i < 12; ++i) acc += xd[i];
-    if (!M<T>::finite(acc)) {
+        for (int i = 1; i < 12; ++i) acc += xd[i];
+        if (!M<T>::finite(acc)) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) xd[i] = M<T>::finite(xd[i]) ? xd[i] : T(0);
+            for (int i = 0; i < 12; ++i) xd[i] = M<T>::finite(xd[i]) ? xd[i] : T(0);
+        }
+    } else {
+        // fp32: guard first (NaN -> 0 like :496-501; an infinity is left for the clamp, which the reference also applies
+        // before its finiteness test), then one v_med3_f32 per clamped derivative.
+        T acc = xd[0];
+#pragma unroll
+        for (int i = 1; i < 12; ++i) acc += xd[i];
+        if (!M<T>::finite(acc)) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) xd[i] = (xd[i] != xd[i]) ? T(0) : xd[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) xd[i] = M<T>::finite(xd[i]) ? xd[i] : T(0);
+#pragma unroll
+            for (int i = 6; i < 9; ++i) xd[i] = M<T>::finite(xd[i]) ? xd[i] : T(0);
+        }
+#pragma unroll
+        for (int i = 9; i < 12; ++i) xd[i] = clipf(xd[i], -P.max_ang_acc, P.max_ang_acc);
+#pragma unroll
+        for (int i = 3; i < 6; ++i) xd[i] = clipf(xd[i], -P.max_acc, P.max_acc);
     }
 }
 
@@ -304,29 +359,10 @@ template <typename S, typename T> FD_DEV S wrap_state_angle(S a)
     }
 }
 
-// ----- Simplified6DOF.step: RK4 + post-clamps, simplified_6dof.py:247-291 --------------------------------
+// ----- post-step clamps of Simplified6DOF.step, simplified_6dof.py:256-291 (in the storage type) -------------
 template <typename S, typename T>
-FD_DEV void rk4_step(const Params<T>& P, const Limits<S>& Lm, const Controls<T>& C, S (&x)[FD_NX], S dt)
+FD_DEV void post_step(const Limits<S>& Lm, S (&x)[FD_NX])
 {
-    T xt[FD_NX], k[FD_NX];
-    S acc[FD_NX];
-    const T hdt = T(S(0.5) * dt), fdt = T(dt);
-#pragma unroll
-    for (int i = 0; i < 12; ++i) xt[i] = T(x[i]);
-    dynamics<T>(P, C, xt, k);                                        // k1
-#pragma unroll
-    for (int i = 0; i < 12; ++i) { acc[i] = S(k[i]); xt[i] = T(x[i] + S(hdt) * S(k[i])); }
-    dynamics<T>(P, C, xt, k);                                        // k2
-#pragma unroll
-    for (int i = 0; i < 12; ++i) { acc[i] += S(2) * S(k[i]); xt[i] = T(x[i] + S(hdt) * S(k[i])); }
-    dynamics<T>(P, C, xt, k);                                        // k3
-#pragma unroll
-    for (int i = 0; i < 12; ++i) { acc[i] += S(2) * S(k[i]); xt[i] = T(x[i] + S(fdt) * S(k[i])); }
-    dynamics<T>(P, C, xt, k);                                        // k4
-    const S dt6 = dt / S(6);
-#pragma unroll
-    for (int i = 0; i < 12; ++i) x[i] = x[i] + dt6 * (acc[i] + S(k[i]));              // :253
-
 #pragma unroll
     for (int i = 0; i < 3; ++i) {                                                      // :258 nan_to_num
         const S v = x[i];
@@ -343,12 +379,82 @@ FD_DEV void rk4_step(const Params<T>& P, const Limits<S>& Lm, const Controls<T>&
         x[2] = S(0);
         x[5] = x[5] > S(0) ? x[5] : S(0);
     }
-    S accs = x[0];                                                                     // :286-291, same trick
+    S accs = x[0];                                                                     // :286-291: all finite <=> sum finite
 #pragma unroll
     for (int i = 1; i < 12; ++i) accs += x[i];
     if (!M<S>::finite(accs)) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) x[i] = M<S>::finite(x[i]) ? x[i] : S(0);
+    }
+}
+
+// ----- Simplified6DOF.step x n_sub: RK4 + post-clamps, simplified_6dof.py:247-291 ------------------------
+// fp64 evaluation (T = double): the reference's operation order, every clamp applied every step.
+// fp32 evaluation (T = float): the four stages and their weighted sum run entirely in fp32 from an fp32 copy of the
+//   state; the storage type S sees ONE add per word per step (x += S(dt/6 * sum)) -- that add is what keeps the
+//   "mixed" variant inside the 1e-4 gate.  The clamps/wraps are tested on the fp32 copy with one combined predicate
+//   and the (rare) fix-up runs under a wave-level branch.
+template <typename S, typename T>
+FD_DEV void rk4_substeps(const Params<T>& P, const Limits<S>& Lm, const Controls<T>& C, S (&x)[FD_NX], S dt, int n_sub)
+{
+    if constexpr (sizeof(T) == 8) {
+        for (int s = 0; s < n_sub; ++s) {
+            T xt[FD_NX], k[FD_NX];
+            S acc[FD_NX];
+            const T hdt = T(S(0.5) * dt), fdt = T(dt);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) xt[i] = T(x[i]);
+            dynamics<T>(P, C, xt, k);                                        // k1
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { acc[i] = S(k[i]); xt[i] = T(x[i] + S(hdt) * S(k[i])); }
+            dynamics<T>(P, C, xt, k);                                        // k2
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { acc[i] += S(2) * S(k[i]); xt[i] = T(x[i] + S(hdt) * S(k[i])); }
+            dynamics<T>(P, C, xt, k);                                        // k3
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { acc[i] += S(2) * S(k[i]); xt[i] = T(x[i] + S(fdt) * S(k[i])); }
+            dynamics<T>(P, C, xt, k);                                        // k4
+            const S dt6 = dt / S(6);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) x[i] = x[i] + dt6 * (acc[i] + S(k[i]));              // :253
+            post_step<S, T>(Lm, x);
+        }
+    } else {
+        constexpr bool HW = sizeof(S) == 4;                                  // pure-fp32 variant: hardware sin/cos
+        const T hdt = T(S(0.5) * dt), fdt = T(dt), dt6 = T(dt / S(6));
+        const T max_vel = T(Lm.max_vel), max_pitch = T(Lm.max_pitch), max_rate = T(Lm.max_rate);
+        T x0[FD_NX];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) x0[i] = T(x[i]);
+        for (int s = 0; s < n_sub; ++s) {
+            T xt[FD_NX], k[FD_NX], acc[FD_NX];
+            dynamics<T, HW>(P, C, x0, k);                                        // k1
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { acc[i] = k[i]; xt[i] = x0[i] + hdt * k[i]; }
+            dynamics<T, HW>(P, C, xt, k);                                        // k2
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { acc[i] += T(2) * k[i]; xt[i] = x0[i] + hdt * k[i]; }
+            dynamics<T, HW>(P, C, xt, k);                                        // k3
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { acc[i] += T(2) * k[i]; xt[i] = x0[i] + fdt * k[i]; }
+            dynamics<T, HW>(P, C, xt, k);                                        // k4
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { x[i] += S(dt6 * (acc[i] + k[i])); x0[i] = T(x[i]); }
+            // one predicate for every clamp / wrap / guard of :256-291, evaluated on the fp32 copy
+            T sum = x0[0];
+#pragma unroll
+            for (int i = 1; i < 12; ++i) sum += x0[i];
+            const T vmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(x0[3]), __builtin_fabsf(x0[4])), __builtin_fabsf(x0[5]));
+            const T rmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(x0[9]), __builtin_fabsf(x0[10])), __builtin_fabsf(x0[11]));
+            const T amax = __builtin_fmaxf(__builtin_fabsf(x0[6]), __builtin_fabsf(x0[8]));
+            const bool fix = !(vmax <= max_vel) | !(rmax <= max_rate) | !(__builtin_fabsf(x0[7]) <= max_pitch) |
+                             !(amax <= T(FD_PI)) | (x0[2] > T(0)) | !M<T>::finite(sum);
+            if (fix) {
+                post_step<S, T>(Lm, x);
+#pragma unroll
+                for (int i = 0; i < 12; ++i) x0[i] = T(x[i]);
+            }
+        }
     }
 }
 

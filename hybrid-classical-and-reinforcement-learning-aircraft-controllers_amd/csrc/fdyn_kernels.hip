@@ -13,6 +13,7 @@
 #include <stdint.h>
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
 #include "fdyn_core.hpp"
 #include "../../include/fdyn.h"
 
@@ -31,6 +32,25 @@ __device__ __forceinline__ void stage(T* dst, const T* __restrict__ src, int n)
     for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
 }
 
+// Lane -> aircraft map with `lpw` (lanes per wave, 16/32/64) populated lanes per wave64.
+// Why: one lane = one aircraft gives N/64 waves; at the benchmark's N = 65 536 that is exactly ONE wave per SIMD, and a
+// lone wave issues at most one VALU instruction every ~4 cycles while the SIMD-32 retires a wave64 instruction in 2
+// (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost').  Populating only the low `lpw` lanes doubles (lpw = 32) the
+// number of waves for the same N, so each SIMD interleaves two independent instruction streams; the idle issue slots
+// it fills were being wasted anyway.  The host picks lpw from N (fdyn_pick_lpw); wave-level ops (ballot, the LDS
+// observation tile) only ever see the populated lanes.
+struct LaneMap { int64_t i, wave_first; int lane; bool on; };
+__device__ __forceinline__ LaneMap lane_map(int lpw, int64_t n)
+{
+    LaneMap m;
+    m.lane = threadIdx.x & (FD_WAVE - 1);
+    const int64_t wave = (int64_t(blockIdx.x) * FD_BLOCK + threadIdx.x) >> 6;
+    m.wave_first = wave * lpw;
+    m.i = m.wave_first + m.lane;
+    m.on = (m.lane < lpw) && (m.i < n);
+    return m;
+}
+
 __device__ __forceinline__ int lane_type(const uint8_t* __restrict__ type, int64_t i, int n_types)
 {
     int t = type ? int(type[i]) : 0;
@@ -44,13 +64,14 @@ template <typename S, typename T>
 __global__ void __launch_bounds__(FD_BLOCK)
 sixdof_step_kernel(S* __restrict__ xs, const S* __restrict__ us, const uint8_t* __restrict__ type,
                    const double* __restrict__ params, int n_types, int64_t n, S dt_sub, int n_sub,
-                   S* __restrict__ derived_out)
+                   S* __restrict__ derived_out, int lpw)
 {
     __shared__ double s_params[FD_MAX_TYPES * FD_NP];
     stage(s_params, params, n_types * FD_NP);
     __syncthreads();
-    const int64_t i = int64_t(blockIdx.x) * FD_BLOCK + threadIdx.x;
-    if (i >= n) return;
+    const LaneMap lm = lane_map(lpw, n);
+    const int64_t i = lm.i;
+    if (!lm.on) return;
 
     const double* blk = s_params + lane_type(type, i, n_types) * FD_NP;
     Params<T> P; P.load(blk);
@@ -61,7 +82,7 @@ sixdof_step_kernel(S* __restrict__ xs, const S* __restrict__ us, const uint8_t* 
     Controls<T> C;
     C.set(P, us[FD_U_ELEVATOR * n + i], us[FD_U_AILERON * n + i], us[FD_U_RUDDER * n + i], us[FD_U_THROTTLE * n + i]);
 
-    for (int s = 0; s < n_sub; ++s) rk4_step<S, T>(P, Lm, C, x, dt_sub);
+    rk4_substeps<S, T>(P, Lm, C, x, dt_sub, n_sub);
 
 #pragma unroll
     for (int k = 0; k < FD_NX; ++k) xs[k * n + i] = x[k];
@@ -119,7 +140,8 @@ cascade_step_kernel(S* __restrict__ xs, float* __restrict__ pid_state /*[9*3][n]
                     const uint8_t* __restrict__ type, const double* __restrict__ params, int n_types,
                     const float* __restrict__ pid_cfg /*[9][8]*/, const double* __restrict__ consts /*[FD_NC]*/,
                     const double* __restrict__ wps /*[n_wp][4]*/, int n_wp, int64_t n, S dt, int n_steps,
-                    S* __restrict__ surf_out /*[4][n] or null*/, int32_t* __restrict__ reached_total /*[n] or null*/)
+                    S* __restrict__ surf_out /*[4][n] or null*/, int32_t* __restrict__ reached_total /*[n] or null*/,
+                    int lpw)
 {
     __shared__ double s_params[FD_MAX_TYPES * FD_NP];
     __shared__ float s_pid_cfg[FD_NPID * FD_NPC];
@@ -130,8 +152,9 @@ cascade_step_kernel(S* __restrict__ xs, float* __restrict__ pid_state /*[9*3][n]
     for (int k = threadIdx.x; k < FD_NC; k += blockDim.x) s_consts[k] = S(consts[k]);
     for (int k = threadIdx.x; k < n_wp * FD_NWP; k += blockDim.x) s_wps[k] = S(wps[k]);
     __syncthreads();
-    const int64_t i = int64_t(blockIdx.x) * FD_BLOCK + threadIdx.x;
-    if (i >= n) return;
+    const LaneMap lm = lane_map(lpw, n);
+    const int64_t i = lm.i;
+    if (!lm.on) return;
 
     const double* blk = s_params + lane_type(type, i, n_types) * FD_NP;
     Params<T> P; P.load(blk);
@@ -159,7 +182,7 @@ cascade_step_kernel(S* __restrict__ xs, float* __restrict__ pid_state /*[9*3][n]
         surf = waypoint_agent<S>(cfg, st, s_consts, s_wps + idx * FD_NWP, x, d, dt);
         Controls<T> C;
         C.set(P, surf.elevator, surf.aileron, surf.rudder, surf.throttle);
-        rk4_step<S, T>(P, Lm, C, x, dt);
+        rk4_substeps<S, T>(P, Lm, C, x, dt, 1);
     }
 
 #pragma unroll
@@ -316,12 +339,13 @@ __device__ __forceinline__ void fetch_reset_record(const double* __restrict__ po
 
 // coalesced write-out of a wave's 64 x 18 observation tile through LDS (row stride 19 words: conflict-free)
 __device__ __forceinline__ void store_obs_tile(float* tile /*[64*19]*/, const float (&o)[FD_OBS_DIM], int lane,
-                                               float* __restrict__ obs_out, int64_t wave_first, int64_t n)
+                                               float* __restrict__ obs_out, int64_t wave_first, int64_t n, int lpw)
 {
 #pragma unroll
     for (int k = 0; k < FD_OBS_DIM; ++k) tile[lane * (FD_OBS_DIM + 1) + k] = o[k];
     __builtin_amdgcn_wave_barrier();
-    const int64_t valid = (n - wave_first) < FD_WAVE ? (n - wave_first) : FD_WAVE;
+    int64_t valid = n - wave_first;
+    valid = valid < 0 ? 0 : (valid < lpw ? valid : lpw);
     float* dst = obs_out + wave_first * FD_OBS_DIM;
 #pragma unroll
     for (int k = 0; k < FD_OBS_DIM; ++k) {
@@ -336,12 +360,13 @@ template <typename S>
 __global__ void __launch_bounds__(FD_BLOCK)
 rate_env_reset_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict__ eis, float* __restrict__ pid_state,
                       const uint8_t* __restrict__ mask, const double* __restrict__ EC, const double* __restrict__ pool,
-                      int pool_depth, uint64_t seed, float* __restrict__ obs_out, int64_t n)
+                      int pool_depth, uint64_t seed, float* __restrict__ obs_out, int64_t n, int lpw)
 {
     __shared__ float s_tile[FD_BLOCK / FD_WAVE][FD_WAVE * (FD_OBS_DIM + 1)];
-    const int64_t i = int64_t(blockIdx.x) * FD_BLOCK + threadIdx.x;
-    const int lane = threadIdx.x & (FD_WAVE - 1), wave = threadIdx.x / FD_WAVE;
-    const bool active = i < n;
+    const LaneMap lm = lane_map(lpw, n);
+    const int64_t i = lm.i;
+    const int lane = lm.lane, wave = threadIdx.x / FD_WAVE;
+    const bool active = lm.on;
     EnvConsts<S> ec;
     load_env_consts<S>(EC, ec);
     S x[FD_NX];
@@ -371,7 +396,7 @@ rate_env_reset_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restric
         airspeed_altitude<S>(x, airspeed, altitude);
         env_observation<S>(x, e, airspeed, altitude, o);
     }
-    store_obs_tile(s_tile[wave], o, lane, obs_out, i - lane, n);
+    store_obs_tile(s_tile[wave], o, lane, obs_out, lm.wave_first, n, lpw);
 }
 
 template <typename S, typename T>
@@ -387,7 +412,7 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
                      float* __restrict__ obs_out /*[n][18]*/, float* __restrict__ reward_f32, S* __restrict__ reward_full,
                      uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
                      int32_t* __restrict__ ev_count, int32_t* __restrict__ ev_count_next, int32_t* __restrict__ ev_int,
-                     float* __restrict__ ev_flt, int ev_cap, int64_t n)
+                     float* __restrict__ ev_flt, int ev_cap, int64_t n, int lpw)
 {
     __shared__ double s_params[FD_MAX_TYPES * FD_NP];
     __shared__ float s_tile[FD_BLOCK / FD_WAVE][FD_WAVE * (FD_OBS_DIM + 1)];
@@ -401,9 +426,10 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
     }
     __syncthreads();
 
-    const int64_t i = int64_t(blockIdx.x) * FD_BLOCK + threadIdx.x;
-    const int lane = threadIdx.x & (FD_WAVE - 1), wave = threadIdx.x / FD_WAVE;
-    const bool active = i < n;
+    const LaneMap lm = lane_map(lpw, n);
+    const int64_t i = lm.i;
+    const int lane = lm.lane, wave = threadIdx.x / FD_WAVE;
+    const bool active = lm.on;
     EnvConsts<S> ec;
     load_env_consts<S>(EC, ec);
     // double-buffered event counter: this launch appends to *ev_count and clears the OTHER slot for the next
@@ -458,7 +484,7 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
         Controls<T> C;
         C.set(P, a[1], a[0], a[2], a[3]);                                         // action = [ail, elev, rud, thr]
         const S dt_sub = ec.dt / S(ec.n_sub);
-        for (int s = 0; s < ec.n_sub; ++s) rk4_step<S, T>(P, Lm, C, x, dt_sub);
+        rk4_substeps<S, T>(P, Lm, C, x, dt_sub, ec.n_sub);
         e.time += ec.dt;                                                          // :241-242
         step += 1;
 
@@ -554,13 +580,37 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
         eis[FD_EI_STEP * n + i] = step;
         eis[FD_EI_EPISODE * n + i] = episode;
     }
-    store_obs_tile(s_tile[wave], o, lane, obs_out, i - lane, n);
+    store_obs_tile(s_tile[wave], o, lane, obs_out, lm.wave_first, n, lpw);
 }
 
 // =========================================================================================================
 // C-ABI (include/fdyn.h)
 // =========================================================================================================
 static inline unsigned grid_for(int64_t n) { return unsigned((n + FD_BLOCK - 1) / FD_BLOCK); }
+
+// lanes-per-wave policy (see lane_map): enough waves for >= 2 per SIMD on the whole chip, never below 16 lanes.
+static int g_lpw_override = 0, g_simds = 0;
+static int pick_lpw(int64_t n)
+{
+    if (g_lpw_override) return g_lpw_override;
+    if (!g_simds) {
+        int dev = 0; hipDeviceProp_t p;
+        g_simds = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount * 4 : 1024;
+        const char* e = getenv("FDYN_LPW");
+        if (e) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) g_lpw_override = v; }
+        if (g_lpw_override) return g_lpw_override;
+    }
+    // Measured on MI355X at N = 65 536 (mixed env step): lpw 64 -> 67.8 us, 32 -> 99.9 us, 16 -> 182.7 us.  The SIMD
+    // already retires ~1 VALU per 5 cycles from a single wave and only reaches ~1 per 3.4 with four, so doubling the
+    // instruction count to double the wave count loses.  Fully populated waves stay the default.
+    (void)n;
+    return 64;
+}
+static inline unsigned grid_lpw(int64_t n, int lpw)
+{
+    const int64_t waves = (n + lpw - 1) / lpw;
+    return unsigned((waves + (FD_BLOCK / FD_WAVE) - 1) / (FD_BLOCK / FD_WAVE));
+}
 static inline int launch_status() { return int(hipGetLastError()); }
 
 #define FD_CHECK_COMMON(n, n_types)                                       \
@@ -577,6 +627,13 @@ int fdyn_num_substeps(double dt, double dt_physics)
     const double r = dt / dt_physics;
     const long n = long(r);
     return n < 1 ? 1 : int(n);
+}
+
+int fdyn_set_lanes_per_wave(int lpw)
+{   // 0 = automatic (default); 16 / 32 / 64 force the lane population of every fleet kernel (tuning / experiments)
+    if (lpw != 0 && lpw != 16 && lpw != 32 && lpw != 64) return FDYN_ERR_BAD_SIZE;
+    g_lpw_override = lpw;
+    return FDYN_OK;
 }
 
 int fdyn_device_info(int* cu_count, int* wave_size, char* arch, int arch_len)
@@ -602,8 +659,9 @@ int fdyn_device_info(int* cu_count, int* wave_size, char* arch, int arch_len)
         const double dt_sub = dt / n_sub;                                                                    \
         /* simplified_6dof.py:241-245: dt <= min_timestep or > max_timestep raises ValueError (defaults) */ \
         if (!(dt_sub > 1e-6) || dt_sub > 1.0) return FDYN_ERR_BAD_DT;                                        \
-        hipLaunchKernelGGL((sixdof_step_kernel<S, T>), dim3(grid_for(n)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
-                           x, u, type, params, n_types, n, S(dt_sub), n_sub, derived_out);                   \
+        const int lpw = pick_lpw(n);                                                                         \
+        hipLaunchKernelGGL((sixdof_step_kernel<S, T>), dim3(grid_lpw(n, lpw)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
+                           x, u, type, params, n_types, n, S(dt_sub), n_sub, derived_out, lpw);              \
         return launch_status();                                                                              \
     }
 FD_DEFINE_SIXDOF(fdyn_sixdof_step_f64, double, double)
@@ -640,9 +698,10 @@ int fdyn_pid_compute_batch(const float* cfg, int cfg_per_lane, float* state, con
         FD_CHECK_COMMON(n, n_types)                                                                          \
         if (n_wp < 1 || n_wp > FD_MAX_WAYPOINTS || n_steps < 0) return FDYN_ERR_BAD_SIZE;                    \
         if (!(dt > 1e-6) || dt > 1.0) return FDYN_ERR_BAD_DT;                                                \
-        hipLaunchKernelGGL((cascade_step_kernel<S, T>), dim3(grid_for(n)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
+        const int lpw = pick_lpw(n);                                                                         \
+        hipLaunchKernelGGL((cascade_step_kernel<S, T>), dim3(grid_lpw(n, lpw)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
                            x, pid_state, wp_idx, type, params, n_types, pid_cfg, consts, wps, n_wp, n, S(dt), \
-                           n_steps, surf_out, reached_total);                                                \
+                           n_steps, surf_out, reached_total, lpw);                                           \
         return launch_status();                                                                              \
     }
 FD_DEFINE_CASCADE(fdyn_cascade_step_f64, double, double)
@@ -656,8 +715,9 @@ FD_DEFINE_CASCADE(fdyn_cascade_step_f32, float, float)
     {                                                                                                        \
         FD_CHECK_COMMON(n, 1)                                                                                \
         if (pool && pool_depth < 1) return FDYN_ERR_BAD_SIZE;                                                \
-        hipLaunchKernelGGL((rate_env_reset_kernel<S>), dim3(grid_for(n)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
-                           x, e, ei, pid_state, mask, env_consts, pool, pool_depth, seed, obs_out, n);       \
+        const int lpw_r = pick_lpw(n);                                                                       \
+        hipLaunchKernelGGL((rate_env_reset_kernel<S>), dim3(grid_lpw(n, lpw_r)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
+                           x, e, ei, pid_state, mask, env_consts, pool, pool_depth, seed, obs_out, n, lpw_r); \
         return launch_status();                                                                              \
     }                                                                                                        \
     int fdyn_rate_env_step_##SUFFIX(S* x, S* e, int32_t* ei, const uint8_t* type, const double* params,      \
@@ -674,11 +734,12 @@ FD_DEFINE_CASCADE(fdyn_cascade_step_f32, float, float)
         if (!actions && !(pid_state && pid_cfg && casc_consts)) return FDYN_ERR_NULL;                        \
         if (!obs_out || !terminated || !truncated || !env_consts) return FDYN_ERR_NULL;                      \
         if (ev_count && (!ev_int || !ev_flt || ev_cap < 0)) return FDYN_ERR_NULL;                            \
-        hipLaunchKernelGGL((rate_env_step_kernel<S, T>), dim3(grid_for(n)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
+        const int lpw = pick_lpw(n);                                                                         \
+        hipLaunchKernelGGL((rate_env_step_kernel<S, T>), dim3(grid_lpw(n, lpw)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
                            x, e, ei, type, params, n_types, env_consts, actions, pid_state, pid_cfg,         \
                            casc_consts, actions_out, rw_delta, pool, pool_depth, seed, auto_reset, obs_out,  \
                            reward_f32, reward_full, terminated, truncated, ev_count, ev_count_next, ev_int, ev_flt,  \
-                           ev_cap, n);                                                                       \
+                           ev_cap, n, lpw);                                                                  \
         return launch_status();                                                                              \
     }
 FD_DEFINE_ENV(f64, double, double)

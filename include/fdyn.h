@@ -51,6 +51,8 @@ extern "C" {
 int fdyn_abi_version(void);
 int fdyn_num_substeps(double dt, double dt_physics);
 int fdyn_device_info(int* cu_count /*host*/, int* wave_size /*host*/, char* arch /*host*/, int arch_len);
+/* lanes populated per wave64 in the fleet kernels: 0 = automatic (>= 2 waves per SIMD when N allows), or 16/32/64 */
+int fdyn_set_lanes_per_wave(int lpw);
 
 /* ---- physics ------------------------------------------------------------------------------------------------
  * x      [FD_NX][n]  state, updated in place
