@@ -82,6 +82,7 @@ class Workload:
             cfg = PPOConfig(n_steps=args.ppo_steps, n_epochs=args.ppo_epochs, n_minibatches=args.ppo_minibatches)
             self.ppo = RecurrentPPO(self.env, pol, cfg, seed=42)
             self.policy_flops = pol.flops_per_env_step()
+            pol.prepare_inference()
             if w == "rollout":
                 self.units_per_step = n
                 self.desc = (f"PPO rollout step: LSTM policy inference ({args.policy_dtype} GEMMs, {pol.num_parameters()} params) "

@@ -1,0 +1,240 @@
+// lstm_mfma.hip -- the recurrent cell of the rate-controller policy as ONE hand-written MFMA kernel for gfx950.
+//
+//   gates[b, n] = sum_k [x_b | keep_b * h_b][k] * W[n][k] + bias[n]      n in [0, 4H), PyTorch gate order i, f, g, o
+//   c' = sigmoid(f) * keep_b * c + sigmoid(i) * tanh(g) ;  h' = sigmoid(o) * tanh(c')
+//
+// i.e. nn.LSTM's cell for one time step (the reference's policy: learned_controllers/networks/lstm_policy.py:49-61 and
+// sb3_contrib's actor / critic LSTMs), batch 16 384 .. 65 536, H = 256, K = 128 + 256.  The un-fused path (hipBLASLt GEMM
+// -> [B, 4H] gate tensor in HBM -> point-wise kernel) writes and re-reads 134 MB of gates per cell per step; here the
+// gate tile never leaves the accumulators.
+//
+// Tiling for CDNA4 (wave64, v_mfma_f32_32x32x16_bf16, 32 cycles each):
+//   * workgroup = 4 waves = 128 batch rows; wave w owns rows [32w, 32w+32).
+//   * A operand (activations): each wave keeps its 32 x K slab in REGISTERS for the whole kernel -- K/16 fragments of
+//     8 bf16 (lane (r, hf) holds row r, k = 16 s + 8 hf .. +7), loaded once straight from HBM; the episode-start mask
+//     (keep_b) is applied to the h part of the slab as it is loaded.
+//   * B operand (weights): streamed through LDS in chunks of 64 weight rows (a gate PAIR x 32 hidden units) x KC
+//     columns, rows padded by 16 B so a ds_read_b128 of 16 consecutive rows touches all 64 banks once (measured:
+//     SQ_LDS_BANK_CONFLICT = 0).  Every wave reads the same chunk: one global read per workgroup, 4x LDS reuse.  Chunks
+//     ping-pong between two LDS buffers; the next chunk is prefetched into registers under the current chunk's MFMAs.
+//     Two workgroups are resident per CU (50 KB LDS, <= 256 VGPRs each).
+//   * per hidden slice (32 units) a wave makes two passes over K: gates (i, g) -> sigmoid(i) tanh(g), then (f, o).
+//     Lane (c, hf) owns hidden unit c of the slice for 16 batch rows in every 32x32 accumulator, so the cell update is
+//     purely lane-local; h' (bf16) and c' (fp32) go straight from registers to HBM.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "../../include/fdyn.h"
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;            // batch rows per workgroup
+constexpr int NSLICE = 32;         // hidden units per slice
+constexpr int LDS_PAD = 8;         // bf16 elements (16 B) of row padding
+
+__device__ __forceinline__ float sigmoid_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
+__device__ __forceinline__ uint16_t f2bf(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return uint16_t((u >> 16) | 0x40);      // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                               // round to nearest even
+    return uint16_t(u >> 16);
+}
+
+// KX = input width, KH = recurrent width (0 = zero-state layer: no h input, no c_prev, no forget gate).
+//
+// Register budget is what shapes this kernel (256 VGPRs at two waves per SIMD): the activation slab is 96, so the four
+// gates of a slice are produced as two PAIRS -- (i, g) first, folded to sigmoid(i)*tanh(g) (16 registers), then (f, o) --
+// which halves the live accumulators (32) and leaves room to prefetch the next weight chunk into registers while the
+// current chunk's MFMAs run.  Weight chunks (64 rows x KC) ping-pong between two LDS buffers: one barrier per chunk.
+template <int KX, int KH>
+__global__ void __launch_bounds__(256, 2)
+lstm_cell_mfma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const uint16_t* __restrict__ h_prev /*[B][KH] bf16*/,
+                      const float* __restrict__ c_prev /*[B][H]*/, const float* __restrict__ keep /*[B] or null*/,
+                      const uint16_t* __restrict__ W /*[4H][KX+KH] bf16*/, const float* __restrict__ bias /*[4H]*/,
+                      uint16_t* __restrict__ h_out /*[B][H] bf16*/, float* __restrict__ c_out /*[B][H]*/,
+                      float* __restrict__ h_out_f32 /*[B][H] or null*/, int64_t B, int H)
+{
+    constexpr int K = KX + KH;
+    constexpr int KSTEPS = K / 16;
+    constexpr int NCHUNK = (K + 191) / 192;               // K-chunks per pass: 384 -> 2 x 192, 256 -> 2 x 128, 128 -> 1
+    constexpr int KC = K / NCHUNK;
+    constexpr int KC_STEPS = KC / 16;
+    constexpr int ROW = KC + LDS_PAD;                     // padded LDS row (bf16 elements)
+    constexpr bool RECUR = KH > 0;
+    constexpr int THREADS = 256;
+    constexpr int CROWS = 2 * NSLICE;                     // weight rows per chunk: one gate pair x 32 hidden units
+    constexpr int VEC_PER_ROW = KC / 8;
+    constexpr int TOTAL_VEC = CROWS * VEC_PER_ROW;
+    constexpr int NV = TOTAL_VEC / THREADS;               // 16-B vectors each thread moves per chunk (4 or 6)
+    static_assert(TOTAL_VEC % THREADS == 0 && NV <= 6, "chunk must divide evenly over the workgroup");
+    constexpr int BUF = CROWS * ROW;
+    __shared__ __attribute__((aligned(16))) uint16_t s_w[2 * BUF];
+    __shared__ float s_keep[BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hf = lane >> 5;
+    const int64_t row0 = int64_t(blockIdx.x) * BM + wave * 32;
+    const int64_t my_row = row0 + r;                      // A-operand row of this lane
+    const bool row_ok = my_row < B;
+    const int n_slices = H / NSLICE;
+
+    // chunk (sl, pass, ch): 64 weight rows = gates (pass, pass + 2) of hidden units sl*32 .. +31, columns ch*KC .. +KC;
+    // pass 0 = (i, g), pass 1 = (f, o).  Zero-state layers have no f: their pass 1 is o alone (rows 0..31 of the chunk).
+    // Source offset = [uniform: chunk origin] + [per-thread constant: row/vector inside the chunk], so each load is
+    // "scalar base + one 32-bit VGPR offset" and the address math costs 6 registers for the whole kernel.
+    // Staging registers and offsets are named scalars: arrays here end up in scratch memory.
+#define FD_LOFF(I) (((((tid + I * THREADS) / VEC_PER_ROW) >> 5) * 2 * H + (((tid + I * THREADS) / VEC_PER_ROW) & 31)) * K + ((tid + I * THREADS) % VEC_PER_ROW) * 8)
+#define FD_LDST(I) (((tid + I * THREADS) / VEC_PER_ROW) * ROW + ((tid + I * THREADS) % VEC_PER_ROW) * 8)
+    const int loff0 = FD_LOFF(0), loff1 = FD_LOFF(1), loff2 = FD_LOFF(2), loff3 = FD_LOFF(3), loff4 = FD_LOFF(4), loff5 = FD_LOFF(5);
+    const int ldst0 = FD_LDST(0), ldst1 = FD_LDST(1), ldst2 = FD_LDST(2), ldst3 = FD_LDST(3), ldst4 = FD_LDST(4), ldst5 = FD_LDST(5);
+    (void)loff4; (void)loff5; (void)ldst4; (void)ldst5;
+#define FD_ORIGIN(SL, PASS, CH) (W + (int64_t((!RECUR && (PASS) == 1) ? 3 : (PASS)) * H + (SL) * NSLICE) * K + (CH) * KC)
+#define FD_F1(I, ORG) if constexpr (NV > I) stage##I = *reinterpret_cast<const uint4*>((ORG) + loff##I);
+#define FD_C1(I, BUFI) if constexpr (NV > I) *reinterpret_cast<uint4*>(s_w + (BUFI) * BUF + ldst##I) = stage##I;
+#define FD_FETCH(SL, PASS, CH) { const uint16_t* org_ = FD_ORIGIN(SL, PASS, CH); FD_F1(0, org_) FD_F1(1, org_) FD_F1(2, org_) FD_F1(3, org_) FD_F1(4, org_) FD_F1(5, org_) }
+#define FD_COMMIT(BUFI) FD_C1(0, BUFI) FD_C1(1, BUFI) FD_C1(2, BUFI) FD_C1(3, BUFI) FD_C1(4, BUFI) FD_C1(5, BUFI)
+
+    uint4 stage0, stage1, stage2, stage3, stage4, stage5;
+    stage0 = stage1 = stage2 = stage3 = stage4 = stage5 = make_uint4(0, 0, 0, 0);
+    FD_FETCH(0, 0, 0)                                     // start the weight stream before the activation slab
+
+    // ---- A slab -> registers (masked h part).  Branch-free: rows past B read row B-1 (their results are never stored) and
+    // the episode-start mask is a select, so all K/16 loads are in flight together (a guarded load per k-step makes
+    // hipcc branch and drain vmcnt around each one).
+    bf16x8_t a[KSTEPS];
+    {
+        const int64_t lrow = row_ok ? my_row : (B - 1);
+        const float kp = (RECUR && keep) ? keep[lrow] : 1.0f;
+        const uint16_t* xr = x + lrow * KX;
+        const uint16_t* hr = RECUR ? h_prev + lrow * KH : x;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            const int k = 16 * s + 8 * hf;
+            uint4 v;
+            if (16 * s < KX) {
+                v = *reinterpret_cast<const uint4*>(xr + k);
+            } else {
+                v = *reinterpret_cast<const uint4*>(hr + (k - KX));
+                v = (kp != 0.0f) ? v : make_uint4(0, 0, 0, 0);
+            }
+            a[s] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    }
+    if (RECUR) {
+        for (int i = tid; i < BM; i += THREADS) {
+            const int64_t b = int64_t(blockIdx.x) * BM + i;
+            s_keep[i] = (keep && b < B) ? keep[b] : 1.0f;
+        }
+    }
+    FD_COMMIT(0)
+    __syncthreads();
+
+    int step = 0;                                         // chunk counter: buffer = step & 1
+    for (int sl = 0; sl < n_slices; ++sl) {
+        const int col = sl * NSLICE + r;
+        float ig[16];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            f32x16_t acc0, acc1;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc0[e] = 0.0f; acc1[e] = 0.0f; }
+#pragma unroll
+            for (int ch = 0; ch < NCHUNK; ++ch, ++step) {
+                const int buf = step & 1;
+                const bool last_ch = ch == NCHUNK - 1;
+                const bool has_next = !(sl == n_slices - 1 && pass == 1 && last_ch);
+                if (has_next) {                               // next chunk: in flight during this chunk's MFMAs
+                    if (!last_ch) { FD_FETCH(sl, pass, ch + 1) }
+                    else if (pass == 0) { FD_FETCH(sl, 1, 0) }
+                    else { FD_FETCH(sl + 1, 0, 0) }
+                }
+                const uint16_t* wb = s_w + buf * BUF;
+#pragma unroll
+                for (int ks = 0; ks < KC_STEPS; ++ks) {
+                    const bf16x8_t af = a[ch * KC_STEPS + ks];
+                    const uint4 b0 = *reinterpret_cast<const uint4*>(wb + r * ROW + ks * 16 + hf * 8);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8_t, b0), acc0, 0, 0, 0);
+                    if (RECUR || pass == 0) {
+                        const uint4 b1 = *reinterpret_cast<const uint4*>(wb + (NSLICE + r) * ROW + ks * 16 + hf * 8);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8_t, b1), acc1, 0, 0, 0);
+                    }
+                }
+                if (has_next) { FD_COMMIT(buf ^ 1) }
+                __syncthreads();                              // next buffer visible; this buffer free for step + 2
+            }
+            // C/D map of a 32x32 tile: col = lane & 31 (hidden unit), row = (e & 3) + 8 (e >> 2) + 4 hf
+            if (pass == 0) {
+                const float bi = bias[col], bg = bias[2 * H + col];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) ig[e] = sigmoid_(acc0[e] + bi) * tanh_(acc1[e] + bg);
+            } else {
+                const float bo = bias[3 * H + col], bf = RECUR ? bias[H + col] : 0.0f;
+                // Addresses: [per-wave base pointer] + [one 32-bit per-lane offset] + [compile-time row constant * H].
+                // Written as b * H + col per element, LLVM hoists sixteen 64-bit row addresses per output array out of
+                // the slice loop and the activation slab spills.
+                const bool full = row0 + 32 <= B;             // wave-uniform: every row of this wave's tile exists
+                const int lane_off = hf * 4 * H + col;
+                const int64_t wave_off = row0 * H;
+                const int rows_left = int(B - row0 < 32 ? B - row0 : 32);      // rows of this tile that exist
+                float cp[16];                                 // all 16 c_prev loads issued together (clamped row)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int lr = (e & 3) + 8 * (e >> 2) + 4 * hf;
+                    const int off = (full || lr < rows_left) ? lane_off + ((e & 3) + 8 * (e >> 2)) * H : col;
+                    cp[e] = RECUR ? c_prev[wave_off + off] : 0.0f;
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int lr = (e & 3) + 8 * (e >> 2) + 4 * hf;
+                    const int off = lane_off + ((e & 3) + 8 * (e >> 2)) * H;
+                    float c = ig[e];
+                    float go;
+                    if (RECUR) {
+                        c += sigmoid_(acc0[e] + bf) * (s_keep[wave * 32 + lr] * cp[e]);
+                        go = sigmoid_(acc1[e] + bo);
+                    } else {
+                        go = sigmoid_(acc0[e] + bo);
+                    }
+                    const float hv = go * tanh_(c);
+                    if (full || lr < rows_left) {
+                        if (c_out) c_out[wave_off + off] = c;
+                        h_out[wave_off + off] = f2bf(hv);
+                        if (h_out_f32) h_out_f32[wave_off + off] = hv;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int KX, int KH>
+int launch(const void* x, const void* h_prev, const float* c_prev, const float* keep, const void* W, const float* bias,
+           void* h_out, float* c_out, float* h_out_f32, int64_t B, int H, hipStream_t st)
+{
+    hipLaunchKernelGGL((lstm_cell_mfma_kernel<KX, KH>), dim3(unsigned((B + BM - 1) / BM)), dim3(256), 0, st, (const uint16_t*)x,
+                       (const uint16_t*)h_prev, c_prev, keep, (const uint16_t*)W, bias, (uint16_t*)h_out, c_out, h_out_f32, B, H);
+    return int(hipGetLastError());
+}
+
+}  // namespace
+
+extern "C" int fdyn_lstm_cell_mfma(const void* x, int kx, const void* h_prev, int kh, const float* c_prev, const float* keep,
+                                   const void* W, const float* bias, void* h_out, float* c_out, float* h_out_f32,
+                                   int64_t B, int H, void* stream)
+{
+    if (B < 0 || H <= 0 || H % NSLICE) return FDYN_ERR_BAD_SIZE;
+    if (!x || !W || !bias || !h_out) return FDYN_ERR_NULL;
+    if (kh > 0 && (!h_prev || !c_prev)) return FDYN_ERR_NULL;
+    if (B == 0) return FDYN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (kx == 128 && kh == 256) return launch<128, 256>(x, h_prev, c_prev, keep, W, bias, h_out, c_out, h_out_f32, B, H, st);
+    if (kx == 128 && kh == 0) return launch<128, 0>(x, h_prev, c_prev, keep, W, bias, h_out, c_out, h_out_f32, B, H, st);
+    if (kx == 256 && kh == 0) return launch<256, 0>(x, h_prev, c_prev, keep, W, bias, h_out, c_out, h_out_f32, B, H, st);
+    if (kx == 128 && kh == 128) return launch<128, 128>(x, h_prev, c_prev, keep, W, bias, h_out, c_out, h_out_f32, B, H, st);
+    return FDYN_ERR_BAD_SIZE;      // supported (input, recurrent) widths: (128,256) (128,0) (256,0) (128,128)
+}

@@ -129,8 +129,65 @@ class RateLSTMPolicy(nn.Module):
         vf_h, vf_c = _lstm_cell(feats, states.vf_h, states.vf_c, lc.weight_ih_l0, lc.weight_hh_l0, lc.bias_ih_l0, lc.bias_hh_l0)
         return self.pi_net(pi_h), self.vf_net(vf_h), RNNStates(pi_h, pi_c, vf_h, vf_c)
 
+    # ---- fused inference path: every LSTM cell is ONE hand-written MFMA kernel (csrc/lstm_mfma.hip) ---------------
+    def prepare_inference(self):
+        """Snapshot the weights as bf16 [4H, in+H] / fp32 bias tensors for the fused rollout path.  Call after every
+        optimizer phase (RecurrentPPO.collect_rollout does); the training path never reads this cache."""
+        if not self.use_lstm:
+            self._inf = None
+            return
+        fe, bf = self.features_extractor, torch.bfloat16
+
+        def cat(l, k):
+            return torch.cat([getattr(l, f"weight_ih_l{k}"), getattr(l, f"weight_hh_l{k}")], 1).detach().to(bf).contiguous()
+
+        def bias(l, k):
+            return (getattr(l, f"bias_ih_l{k}") + getattr(l, f"bias_hh_l{k}")).detach().float().contiguous()
+        self._inf = {
+            "fe_w": [getattr(fe.lstm, f"weight_ih_l{k}").detach().to(bf).contiguous() for k in range(fe.lstm.num_layers)],
+            "fe_b": [bias(fe.lstm, k) for k in range(fe.lstm.num_layers)],
+            "pi_w": cat(self.lstm_actor, 0), "pi_b": bias(self.lstm_actor, 0),
+            "vf_w": cat(self.lstm_critic, 0), "vf_b": bias(self.lstm_critic, 0),
+        }
+
+    def _fused_ok(self, obs):
+        inf = getattr(self, "_inf", None)
+        return (inf is not None and obs.is_cuda and self.compute_dtype == torch.bfloat16 and not torch.is_grad_enabled()
+                and self.hidden == 256 and all(w.shape[1] in (128, 256) for w in inf["fe_w"]))
+
+    def _core_fused(self, obs, states: RNNStates, keep):
+        from . import _lib
+        lib, inf, B, H = _lib.load(), self._inf, obs.shape[0], self.hidden
+        fe, bf, dev = self.features_extractor, torch.bfloat16, obs.device
+        st = _lib.current_stream()
+        x = fe.embedding(obs)                                            # bf16 under autocast
+        for w, b in zip(inf["fe_w"], inf["fe_b"]):                       # zero-state layers: no h/c input at all
+            h = torch.empty((B, w.shape[0] // 4), dtype=bf, device=dev)
+            _lib.check(lib.fdyn_lstm_cell_mfma(x.data_ptr(), x.shape[1], None, 0, None, None, w.data_ptr(), b.data_ptr(),
+                                               h.data_ptr(), None, None, B, w.shape[0] // 4, st), "lstm_cell_mfma")
+            x = h
+        feats = fe.output_proj(x).contiguous()
+        out = []
+        for w, b, hp, cp in ((inf["pi_w"], inf["pi_b"], states.pi_h, states.pi_c), (inf["vf_w"], inf["vf_b"], states.vf_h, states.vf_c)):
+            hp = hp.to(bf).contiguous()
+            h, c = torch.empty((B, H), dtype=bf, device=dev), torch.empty((B, H), dtype=torch.float32, device=dev)
+            _lib.check(lib.fdyn_lstm_cell_mfma(feats.data_ptr(), feats.shape[1], hp.data_ptr(), H, cp.contiguous().data_ptr(),
+                                               keep.data_ptr(), w.data_ptr(), b.data_ptr(), h.data_ptr(), c.data_ptr(), None,
+                                               B, H, st), "lstm_cell_mfma")
+            out += [h, c]
+        return self.pi_net(out[0]), self.vf_net(out[2]), RNNStates(*out)
+
     def step(self, obs, states: RNNStates, episode_start, deterministic: bool = False):
         """obs [B,18], episode_start [B] (1 where the env was just reset) -> actions, values, log_probs, new states."""
+        if self._fused_ok(obs):
+            keep = (1.0 - episode_start.float()).contiguous()            # the mask is applied inside the kernel
+            with torch.autocast(obs.device.type, dtype=self.compute_dtype):
+                lat_pi, lat_vf, new_states = self._core_fused(obs, states, keep)
+                mean = self.action_net(lat_pi).float()
+                value = self.value_net(lat_vf).float().squeeze(-1)
+            std = self.log_std.exp()
+            actions = mean if deterministic else mean + std * torch.randn_like(mean)
+            return actions, value, self._log_prob(actions, mean), new_states
         states = states.masked(1.0 - episode_start.float())
         with torch.autocast(obs.device.type, dtype=self.compute_dtype, enabled=self.compute_dtype is not None):
             lat_pi, lat_vf, new_states = self._core(obs, states)

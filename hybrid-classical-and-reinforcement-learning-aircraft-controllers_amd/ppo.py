@@ -134,6 +134,7 @@ class RecurrentPPO:
     @torch.no_grad()
     def collect_rollout(self):
         env, pol, cfg = self.env, self.policy, self.cfg
+        pol.prepare_inference()                           # bf16 weight snapshot for the fused MFMA rollout path
         self.rollout_states = self.states
         ev_r, ev_l = [], []
         for t in range(cfg.n_steps):

@@ -129,6 +129,16 @@ int fdyn_lstm_cell_fwd(const void* gates, int gates_bf16, const float* c_prev, f
                        void* act_out, int64_t B, int H, void* stream);
 int fdyn_lstm_cell_bwd(const void* act, int bf16, const float* c_prev, const float* c_new, const void* dh,
                        const float* dc_next, void* dgates, float* dc_prev, int64_t B, int H, void* stream);
+/* The whole LSTM cell step as ONE MFMA kernel (csrc/lstm_mfma.hip): gates = [x | keep*h_prev] W^T + bias on
+ * v_mfma_f32_32x32x16_bf16 with the gate non-linearity and cell update fused on the accumulators (no [B][4H] tensor).
+ * x [B][kx] bf16, h_prev [B][kh] bf16, c_prev [B][H] fp32, keep [B] fp32 or NULL (0 = episode start: zero the state),
+ * W [4H][kx+kh] bf16 (= [W_ih | W_hh], gate order i,f,g,o), bias [4H] fp32 (= b_ih + b_hh).
+ * kh == 0: zero-state layer (the reference's feature-extractor LSTM, lstm_policy.py:75-92): no h/c input.
+ * Outputs h_out [B][H] bf16, c_out [B][H] fp32 (NULL allowed), h_out_f32 [B][H] or NULL.
+ * Supported (kx, kh): (128,256) (128,0) (256,0) (128,128); H % 32 == 0.                                              */
+int fdyn_lstm_cell_mfma(const void* x, int kx, const void* h_prev, int kh, const float* c_prev, const float* keep,
+                        const void* W, const float* bias, void* h_out, float* c_out, float* h_out_f32,
+                        int64_t B, int H, void* stream);
 /* GAE(lambda) over a [T][N] rollout (one lane per env): adv, ret [T][N].  episode_starts[t][n] = 1 if env n was reset
  * before step t; last_values / last_dones [N] describe the state after the final step.                              */
 int fdyn_gae(const float* rewards, const float* values, const float* episode_starts, const float* last_values,

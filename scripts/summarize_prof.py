@@ -36,7 +36,7 @@ if stats:
 # ---- PMC passes: average per dispatch of the hot kernels ------------------------------------------------------
 pmc = defaultdict(lambda: defaultdict(list))
 meta = {}
-for path in glob.glob(os.path.join(prof, "pmc_*", "**", "*_counter_collection.csv"), recursive=True):
+for path in glob.glob(os.path.join(prof, "p*", "**", "*_counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(path)):
         k = short(r["Kernel_Name"])
         if not any(s in k for s in ("rate_env", "sixdof", "cascade", "lstm", "gate")):

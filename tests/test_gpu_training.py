@@ -93,3 +93,68 @@ def test_policy_gpu_matches_cpu_forward():
     a_g, v_g, lp_g, s_g = pg.step(obs.cuda(), pg.initial_state(64, "cuda"), torch.zeros(64, device="cuda"), deterministic=True)
     assert (a_g.cpu() - a_c).abs().max() < 1e-4 and (v_g.cpu() - v_c).abs().max() < 1e-4
     assert (s_g.pi_c.cpu() - s_c.pi_c).abs().max() < 1e-4
+
+
+def _mfma_cell(x, h, c, keep, W, bias, H):
+    from hcrl_amd import _lib
+    lib = _lib.load()
+    B = x.shape[0]
+    kh = 0 if h is None else h.shape[1]
+    h_out = torch.empty((B, H), dtype=torch.bfloat16, device="cuda")
+    c_out = torch.empty((B, H), dtype=torch.float32, device="cuda")
+    h32 = torch.empty((B, H), dtype=torch.float32, device="cuda")
+    _lib.check(lib.fdyn_lstm_cell_mfma(x.data_ptr(), x.shape[1], _lib.ptr(h), kh, _lib.ptr(c), _lib.ptr(keep), W.data_ptr(),
+                                       bias.data_ptr(), h_out.data_ptr(), c_out.data_ptr(), h32.data_ptr(), B, H,
+                                       _lib.current_stream()), "lstm_cell_mfma")
+    return h_out, c_out, h32
+
+
+@pytest.mark.parametrize("B", [128, 777, 4096])
+@pytest.mark.parametrize("kx,kh", [(128, 256), (128, 0), (256, 0), (128, 128)])
+def test_lstm_mfma_cell_matches_plain_torch_fp32(B, kx, kh):
+    """Hand-written MFMA LSTM cell vs plain PyTorch fp32 on the same bf16-rounded inputs (asymmetric random data, so a
+    transposed or permuted fragment map cannot pass)."""
+    torch.manual_seed(B + kx + kh)
+    H = 256
+    x = (torch.randn(B, kx, device="cuda") * 0.7).bfloat16()
+    W = (torch.randn(4 * H, kx + kh, device="cuda") * 0.08).bfloat16()
+    bias = torch.randn(4 * H, device="cuda") * 0.3
+    if kh:
+        h = (torch.randn(B, kh, device="cuda") * 0.5).bfloat16()
+        c = torch.randn(B, H, device="cuda")
+        keep = (torch.rand(B, device="cuda") > 0.25).float()
+        xin = torch.cat([x.float(), h.float() * keep[:, None]], 1)
+        c_eff = c * keep[:, None]
+    else:
+        h = c = keep = None
+        xin, c_eff = x.float(), None
+    gates = xin @ W.float().t() + bias
+    i, f, g, o = gates.chunk(4, 1)
+    c_ref = torch.sigmoid(i) * torch.tanh(g) + (torch.sigmoid(f) * c_eff if kh else 0)
+    h_ref = torch.sigmoid(o) * torch.tanh(c_ref)
+    h_out, c_out, h32 = _mfma_cell(x, h, c, keep, W, bias, H)
+    assert (c_out - c_ref).abs().max() < 2e-3, float((c_out - c_ref).abs().max())
+    assert (h32 - h_ref).abs().max() < 2e-3
+    assert (h_out.float() - h_ref).abs().max() < 1e-2
+
+
+def test_fused_rollout_step_matches_unfused_bf16_path():
+    torch.manual_seed(0)
+    p = RateLSTMPolicy(compute_dtype=torch.bfloat16).cuda()
+    B = 300
+    obs = torch.randn(B, 18, device="cuda")
+    st = p.initial_state(B, "cuda")
+    st = type(st)(*(t + 0.3 * torch.randn_like(t) for t in st))
+    start = (torch.rand(B, device="cuda") < 0.3).float()
+    with torch.no_grad():
+        a0, v0, lp0, s0 = p.step(obs, st, start, deterministic=True)           # un-fused (no inference cache yet)
+        p.prepare_inference()
+        a1, v1, lp1, s1 = p.step(obs, st, start, deterministic=True)           # fused MFMA cells
+    assert (a0 - a1).abs().max() < 3e-2 and (v0 - v1).abs().max() < 5e-2
+    assert (s0.pi_c - s1.pi_c).abs().max() < 3e-2 and (s0.vf_h.float() - s1.vf_h.float()).abs().max() < 3e-2
+
+
+def test_lstm_mfma_cell_full_chip_variant():
+    """B >= 256 rows x CU count selects the 8-wave double-buffered workgroup; ragged tail included."""
+    test_lstm_mfma_cell_matches_plain_torch_fp32(256 * 256 + 77, 128, 256)
+    test_lstm_mfma_cell_matches_plain_torch_fp32(256 * 256, 256, 0)
