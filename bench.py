@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--policy-dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU-side rendezvous for rehearsals")
+    ap.add_argument("--device-index", type=int, default=-1, help="force every rank onto this GPU (1-GPU rehearsal of N>1)")
     ap.add_argument("--ppo-steps", type=int, default=16, help="rollout length per PPO iteration (train workload)")
     ap.add_argument("--ppo-epochs", type=int, default=2)
     ap.add_argument("--ppo-minibatches", type=int, default=8)
@@ -54,11 +56,15 @@ def setup_dist(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
+    dev = args.device_index if args.device_index >= 0 else local
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo")
     return world, rank, local
 
 
@@ -193,7 +199,7 @@ def timed_region(wl, args, world):
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
     if world > 1:
-        t = torch.tensor([wall], device="cuda", dtype=torch.float64)
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         wall = float(t.item())
     return wall, dev_ms, ("hipGraph x%d" % gsteps) if graph is not None else "eager"

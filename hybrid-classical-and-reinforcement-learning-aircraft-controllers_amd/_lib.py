@@ -62,7 +62,16 @@ def load():
     return _lib
 
 
+_SYNC_DEBUG = bool(os.environ.get("FDYN_SYNC_DEBUG"))
+
+
 def check(rc, what="fdyn call"):
+    if _SYNC_DEBUG:                       # debugging aid: localise an asynchronous GPU fault to one launch
+        import sys
+        import torch
+        print(f"[fdyn] {what} rc={rc} ...", end="", file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
+        print(" done", file=sys.stderr, flush=True)
     if rc == FDYN_OK:
         return
     if rc == FDYN_ERR_BAD_DT:

@@ -84,7 +84,8 @@ lstm_cell_mfma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const uin
     const int n_slices = H / NSLICE;
 
     // chunk (sl, pass, ch): 64 weight rows = gates (pass, pass + 2) of hidden units sl*32 .. +31, columns ch*KC .. +KC;
-    // pass 0 = (i, g), pass 1 = (f, o).  Zero-state layers have no f: their pass 1 is o alone (rows 0..31 of the chunk).
+    // pass 0 = (i, g), pass 1 = (f, o).  Zero-state layers have no use for f: their pass 1 still stages (f, o) -- every
+    // address stays inside W -- but only multiplies the o half.
     // Source offset = [uniform: chunk origin] + [per-thread constant: row/vector inside the chunk], so each load is
     // "scalar base + one 32-bit VGPR offset" and the address math costs 6 registers for the whole kernel.
     // Staging registers and offsets are named scalars: arrays here end up in scratch memory.
@@ -93,7 +94,7 @@ lstm_cell_mfma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const uin
     const int loff0 = FD_LOFF(0), loff1 = FD_LOFF(1), loff2 = FD_LOFF(2), loff3 = FD_LOFF(3), loff4 = FD_LOFF(4), loff5 = FD_LOFF(5);
     const int ldst0 = FD_LDST(0), ldst1 = FD_LDST(1), ldst2 = FD_LDST(2), ldst3 = FD_LDST(3), ldst4 = FD_LDST(4), ldst5 = FD_LDST(5);
     (void)loff4; (void)loff5; (void)ldst4; (void)ldst5;
-#define FD_ORIGIN(SL, PASS, CH) (W + (int64_t((!RECUR && (PASS) == 1) ? 3 : (PASS)) * H + (SL) * NSLICE) * K + (CH) * KC)
+#define FD_ORIGIN(SL, PASS, CH) (W + (int64_t(PASS) * H + (SL) * NSLICE) * K + (CH) * KC)
 #define FD_F1(I, ORG) if constexpr (NV > I) stage##I = *reinterpret_cast<const uint4*>((ORG) + loff##I);
 #define FD_C1(I, BUFI) if constexpr (NV > I) *reinterpret_cast<uint4*>(s_w + (BUFI) * BUF + ldst##I) = stage##I;
 #define FD_FETCH(SL, PASS, CH) { const uint16_t* org_ = FD_ORIGIN(SL, PASS, CH); FD_F1(0, org_) FD_F1(1, org_) FD_F1(2, org_) FD_F1(3, org_) FD_F1(4, org_) FD_F1(5, org_) }
@@ -157,12 +158,12 @@ lstm_cell_mfma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const uin
 #pragma unroll
                 for (int ks = 0; ks < KC_STEPS; ++ks) {
                     const bf16x8_t af = a[ch * KC_STEPS + ks];
-                    const uint4 b0 = *reinterpret_cast<const uint4*>(wb + r * ROW + ks * 16 + hf * 8);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8_t, b0), acc0, 0, 0, 0);
-                    if (RECUR || pass == 0) {
-                        const uint4 b1 = *reinterpret_cast<const uint4*>(wb + (NSLICE + r) * ROW + ks * 16 + hf * 8);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8_t, b1), acc1, 0, 0, 0);
+                    if (RECUR || pass == 0) {                 // rows 0..31 of the chunk: gate i (pass 0) / f (pass 1)
+                        const uint4 b0 = *reinterpret_cast<const uint4*>(wb + r * ROW + ks * 16 + hf * 8);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8_t, b0), acc0, 0, 0, 0);
                     }
+                    const uint4 b1 = *reinterpret_cast<const uint4*>(wb + (NSLICE + r) * ROW + ks * 16 + hf * 8);   // g / o
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8_t, b1), acc1, 0, 0, 0);
                 }
                 if (has_next) { FD_COMMIT(buf ^ 1) }
                 __syncthreads();                              // next buffer visible; this buffer free for step + 2
@@ -179,8 +180,8 @@ lstm_cell_mfma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const uin
                 // the slice loop and the activation slab spills.
                 const bool full = row0 + 32 <= B;             // wave-uniform: every row of this wave's tile exists
                 const int lane_off = hf * 4 * H + col;
-                const int64_t wave_off = row0 * H;
-                const int rows_left = int(B - row0 < 32 ? B - row0 : 32);      // rows of this tile that exist
+                const int64_t wave_off = (row0 < B ? row0 : 0) * H;      // a wave wholly past B reads row 0, stores nothing
+                const int rows_left = row0 < B ? int(B - row0 < 32 ? B - row0 : 32) : 0;   // rows of this tile that exist
                 float cp[16];                                 // all 16 c_prev loads issued together (clamped row)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
@@ -194,12 +195,8 @@ lstm_cell_mfma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const uin
                     const int off = lane_off + ((e & 3) + 8 * (e >> 2)) * H;
                     float c = ig[e];
                     float go;
-                    if (RECUR) {
-                        c += sigmoid_(acc0[e] + bf) * (s_keep[wave * 32 + lr] * cp[e]);
-                        go = sigmoid_(acc1[e] + bo);
-                    } else {
-                        go = sigmoid_(acc0[e] + bo);
-                    }
+                    if (RECUR) c += sigmoid_(acc0[e] + bf) * (s_keep[wave * 32 + lr] * cp[e]);
+                    go = sigmoid_(acc1[e] + bo);
                     const float hv = go * tanh_(c);
                     if (full || lr < rows_left) {
                         if (c_out) c_out[wave_off + off] = c;

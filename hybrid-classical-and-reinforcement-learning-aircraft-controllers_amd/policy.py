@@ -18,6 +18,7 @@ Every matmul is a `[B, K] x [K, 4H]` GEMM that rocBLAS/hipBLASLt runs on MFMA; w
 the GEMMs run in bf16 with fp32 accumulate (autocast), the cell state and the PPO loss stay fp32.
 """
 import math
+import os
 from typing import NamedTuple, Optional, Tuple
 
 import torch
@@ -151,7 +152,7 @@ class RateLSTMPolicy(nn.Module):
         }
 
     def _fused_ok(self, obs):
-        inf = getattr(self, "_inf", None)
+        inf = None if os.environ.get("FDYN_NO_MFMA") else getattr(self, "_inf", None)
         return (inf is not None and obs.is_cuda and self.compute_dtype == torch.bfloat16 and not torch.is_grad_enabled()
                 and self.hidden == 256 and all(w.shape[1] in (128, 256) for w in inf["fe_w"]))
 

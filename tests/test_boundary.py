@@ -126,3 +126,27 @@ def test_reset_pool_follows_reference_stream_order():
                        [20.6181, 192.6071, 0.1214717, 0.05165746, 0.980294], rtol=1e-6)
     ec = samplers.env_consts("easy", 10.0, 0.02, "step")
     assert ec[L.FD_EC_MAX_STEPS] == 500 and ec[L.FD_EC_DIFFICULTY_SCALE] == 0.3
+
+
+@pytest.mark.parametrize("kx,kh", [(128, 256), (128, 0), (256, 0), (128, 128)])
+def test_lstm_mfma_weight_stream_stays_inside_w(kx, kh):
+    """Host-side replay of the weight-chunk address arithmetic of csrc/lstm_mfma.hip (FD_ORIGIN + FD_LOFF): every 16-byte
+    vector any thread fetches must lie inside W[4H][K].  (An earlier revision read gate 3 + 2 = 5 for the zero-state layers:
+    harmless values, but a memory fault whenever W sat at the end of a mapping.)"""
+    H, K, threads, nslice = 256, kx + kh, 256, 32
+    nchunk = (K + 191) // 192
+    kc = K // nchunk
+    vec_per_row = kc // 8
+    nv = 2 * nslice * vec_per_row // threads
+    tid = np.arange(threads)
+    worst = 0
+    for i in range(nv):
+        v = tid + i * threads
+        row = v // vec_per_row
+        loff = ((row >> 5) * 2 * H + (row & 31)) * K + (v % vec_per_row) * 8
+        for sl in range(H // nslice):
+            for p in range(2):
+                for ch in range(nchunk):
+                    origin = (p * H + sl * nslice) * K + ch * kc
+                    worst = max(worst, int((origin + loff).max()) + 8)
+    assert worst <= 4 * H * K, (worst, 4 * H * K)
