@@ -102,7 +102,14 @@ lstm_cell_mfma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const uin
 
     uint4 stage0, stage1, stage2, stage3, stage4, stage5;
     stage0 = stage1 = stage2 = stage3 = stage4 = stage5 = make_uint4(0, 0, 0, 0);
-    FD_FETCH(0, 0, 0)                                     // start the weight stream before the activation slab
+    // Workgroups walk the hidden slices in ROTATED order.  In natural order all 512 workgroups stream the same 25 KB of W
+    // at the same moment: in each XCD's L2 one hot line is served to 64 workgroups while the other channels idle (measured:
+    // the weight stream alone took 82 us = 0.6 TB/s per XCD).  Blocks b and b + 8 share an XCD (round-robin dispatch), so
+    // the rotation mixes b and b / 8: the workgroups of one XCD then have 8 different slices in flight.  Speed only -- any
+    // placement gives the same result.
+    const int sl_start = int((blockIdx.x + (blockIdx.x >> 3)) % unsigned(n_slices));   // b%8 and b/8 both rotate (measured best)
+#define FD_SL(I) (((I) + sl_start) % n_slices)
+    FD_FETCH(FD_SL(0), 0, 0)                              // start the weight stream before the activation slab
 
     // ---- A slab -> registers (masked h part).  Branch-free: rows past B read row B-1 (their results are never stored) and
     // the episode-start mask is a select, so all K/16 loads are in flight together (a guarded load per k-step makes
@@ -136,7 +143,8 @@ lstm_cell_mfma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const uin
     __syncthreads();
 
     int step = 0;                                         // chunk counter: buffer = step & 1
-    for (int sl = 0; sl < n_slices; ++sl) {
+    for (int si = 0; si < n_slices; ++si) {
+        const int sl = FD_SL(si);
         const int col = sl * NSLICE + r;
         float ig[16];
 #pragma unroll
@@ -148,11 +156,11 @@ lstm_cell_mfma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const uin
             for (int ch = 0; ch < NCHUNK; ++ch, ++step) {
                 const int buf = step & 1;
                 const bool last_ch = ch == NCHUNK - 1;
-                const bool has_next = !(sl == n_slices - 1 && pass == 1 && last_ch);
+                const bool has_next = !(si == n_slices - 1 && pass == 1 && last_ch);
                 if (has_next) {                               // next chunk: in flight during this chunk's MFMAs
                     if (!last_ch) { FD_FETCH(sl, pass, ch + 1) }
                     else if (pass == 0) { FD_FETCH(sl, 1, 0) }
-                    else { FD_FETCH(sl + 1, 0, 0) }
+                    else { FD_FETCH(FD_SL(si + 1), 0, 0) }
                 }
                 const uint16_t* wb = s_w + buf * BUF;
 #pragma unroll

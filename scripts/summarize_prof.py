@@ -17,7 +17,7 @@ os.makedirs(out, exist_ok=True)
 
 
 def short(name):
-    name = name.replace("void ", "")
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "")
     return name.split("(")[0][:90]
 
 
