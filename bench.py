@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--graph", type=int, default=1, help="replay the step loop from a hipGraph (1) or launch eagerly (0)")
     ap.add_argument("--graph-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the short secondary measurements of the default run")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--policy-dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU-side rendezvous for rehearsals")
@@ -205,6 +206,26 @@ def timed_region(wl, args, world):
     return wall, dev_ms, ("hipGraph x%d" % gsteps) if graph is not None else "eager"
 
 
+def extras(args):
+    """Short secondary measurements (same GPU, same batch) reported beside the headline; each ~1-3 s."""
+    import copy
+    res = {}
+    for wl_name, steps, warm in (("physics", 400, 40), ("cascade", 100, 10), ("rollout", 60, 6), ("train", 2, 1)):
+        try:
+            a = copy.copy(args)
+            a.workload, a.steps, a.warmup = wl_name, steps, warm
+            wl = Workload(a, 0)
+            wall, dev_ms, mode = timed_region(wl, a, 1)
+            res[wl_name] = {"value": wl.units_per_step * steps / wall, "ms_per_step": wall * 1e3 / steps,
+                            "unit": "env-steps/s" if wl_name in ("rollout", "train") else "aircraft-steps/s",
+                            "workload": wl.desc}
+            del wl
+            torch.cuda.empty_cache()
+        except Exception as ex:
+            res[wl_name] = {"error": repr(ex)}
+    return res
+
+
 def cpu_baseline(args):
     """The CPU oracle (test infrastructure) timed on this box's host cores on a bounded sample of the same workload."""
     from oracle import oracle as orc
@@ -285,6 +306,8 @@ def main():
         out["policy"] = {"flops_per_env_step_fwd": wl.policy_flops, "achieved_tflops": pf, "dtype": args.policy_dtype,
                          "peak_tflops_dense": 2500.0 if args.policy_dtype == "bf16" else 157.3,
                          "frac": pf / (2500.0 if args.policy_dtype == "bf16" else 157.3)}
+    if world == 1 and args.workload == "env" and not args.no_extras:
+        out["extras"] = extras(args)
     if world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(args)

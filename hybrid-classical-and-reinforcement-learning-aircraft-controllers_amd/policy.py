@@ -176,8 +176,12 @@ class RateLSTMPolicy(nn.Module):
         lib, inf, B, H = _lib.load(), self._inf, obs.shape[0], self.hidden
         bf, dev = torch.bfloat16, obs.device
         st = _lib.current_stream()
+        def shapes_ok(x_, w_, b_, kh_):      # the kernel trusts its sizes: check them on the host before every launch
+            return (x_.is_contiguous() and x_.dtype == bf and x_.shape == (B, w_.shape[1] - kh_) and w_.is_contiguous()
+                    and w_.dtype == bf and b_.dtype == torch.float32 and b_.numel() == w_.shape[0] and w_.shape[0] % 128 == 0)
         x = self._mlp_bf16(obs.to(bf), inf["emb"])
         for w, b in zip(inf["fe_w"], inf["fe_b"]):                       # zero-state layers: no h/c input at all
+            assert shapes_ok(x, w, b, 0), "lstm_cell_mfma operand shapes"
             h = torch.empty((B, w.shape[0] // 4), dtype=bf, device=dev)
             _lib.check(lib.fdyn_lstm_cell_mfma(x.data_ptr(), x.shape[1], None, 0, None, None, w.data_ptr(), b.data_ptr(),
                                                h.data_ptr(), None, None, B, w.shape[0] // 4, st), "lstm_cell_mfma")
@@ -185,9 +189,11 @@ class RateLSTMPolicy(nn.Module):
         feats = self._mlp_bf16(x, inf["proj"])
         out = []
         for w, b, hp, cp in ((inf["pi_w"], inf["pi_b"], states.pi_h, states.pi_c), (inf["vf_w"], inf["vf_b"], states.vf_h, states.vf_c)):
-            hp = hp.to(bf).contiguous()
+            hp, cp = hp.to(bf).contiguous(), cp.float().contiguous()
+            assert shapes_ok(feats, w, b, H) and hp.shape == (B, H) and cp.shape == (B, H) and keep.shape == (B,) \
+                and w.shape[0] == 4 * H, "lstm_cell_mfma operand shapes"
             h, c = torch.empty((B, H), dtype=bf, device=dev), torch.empty((B, H), dtype=torch.float32, device=dev)
-            _lib.check(lib.fdyn_lstm_cell_mfma(feats.data_ptr(), feats.shape[1], hp.data_ptr(), H, cp.contiguous().data_ptr(),
+            _lib.check(lib.fdyn_lstm_cell_mfma(feats.data_ptr(), feats.shape[1], hp.data_ptr(), H, cp.data_ptr(),
                                                keep.data_ptr(), w.data_ptr(), b.data_ptr(), h.data_ptr(), c.data_ptr(), None,
                                                B, H, st), "lstm_cell_mfma")
             out += [h, c]

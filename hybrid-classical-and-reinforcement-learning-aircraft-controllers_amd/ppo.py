@@ -28,7 +28,8 @@ from .policy import RateLSTMPolicy, RNNStates
 class PPOConfig:
     learning_rate: float = 3.0e-4
     n_steps: int = 64            # per-env rollout length (reference: 2048 with 4 envs; here N is 10^4..10^5)
-    n_minibatches: int = 8       # env slices per epoch (reference expresses this as batch_size)
+    n_minibatches: int = 4       # env slices per epoch (reference expresses this as batch_size); big slices keep the
+                                 # per-timestep BPTT GEMMs wide enough to fill 256 CUs (8 -> 2 slices: 235 -> 141 ms/iter)
     n_epochs: int = 10
     gamma: float = 0.99
     gae_lambda: float = 0.95

@@ -158,3 +158,21 @@ def test_lstm_mfma_cell_full_chip_variant():
     """B >= 256 rows x CU count selects the 8-wave double-buffered workgroup; ragged tail included."""
     test_lstm_mfma_cell_matches_plain_torch_fp32(256 * 256 + 77, 128, 256)
     test_lstm_mfma_cell_matches_plain_torch_fp32(256 * 256, 256, 0)
+
+
+def test_train_rate_cli_end_to_end(tmp_path):
+    """The reference-shaped CLI (config YAML + curriculum) runs end to end on a tiny budget and writes a checkpoint."""
+    import yaml
+    from hcrl_amd import train_rate
+    cfg = yaml.safe_load(open(train_rate.DEFAULT_CONFIG))
+    cfg["training"]["n_envs"] = 512
+    cfg["ppo"]["n_steps"] = 8
+    cfg["ppo"]["n_epochs"] = 1
+    for ph in cfg["curriculum"]["phases"]:
+        ph["timesteps"] = 512 * 8
+    cfg["paths"]["model_save_dir"] = str(tmp_path / "ckpt")
+    p = tmp_path / "cfg.yaml"
+    p.write_text(yaml.safe_dump(cfg))
+    train_rate.main(["--config", str(p), "--bf16", "--bc-pretrain", "1"])
+    ck = torch.load(tmp_path / "ckpt" / "final_model.pt", weights_only=True)
+    assert ck["num_timesteps"] == 3 * 512 * 8 and "policy" in ck
