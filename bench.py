@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--device-index", type=int, default=-1, help="force every rank onto this GPU (1-GPU rehearsal of N>1)")
     ap.add_argument("--ppo-steps", type=int, default=16, help="rollout length per PPO iteration (train workload)")
     ap.add_argument("--ppo-epochs", type=int, default=2)
-    ap.add_argument("--ppo-minibatches", type=int, default=8)
+    ap.add_argument("--ppo-minibatches", type=int, default=2)
     return ap.parse_args()
 
 

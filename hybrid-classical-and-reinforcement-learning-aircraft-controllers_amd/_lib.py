@@ -16,7 +16,7 @@ _i, _i64, _u64, _d, _f = C.c_int, C.c_int64, C.c_uint64, C.c_double, C.c_float
 _SIXDOF = [_p, _p, _p, _p, _i, _i64, _d, _i, _p, _p]
 _CASCADE = [_p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i64, _d, _i, _p, _p, _p]
 _ENV_RESET = [_p, _p, _p, _p, _p, _p, _p, _i, _u64, _p, _i64, _p]
-_ENV_STEP = [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _u64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+_ENV_STEP = [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _u64, _i, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p,
              _i, _i64, _p]
 
 SIGNATURES = {

@@ -408,7 +408,7 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
                      float* __restrict__ pid_state /*[3*3][n], PID mode*/, const float* __restrict__ pid_cfg /*[9][8]*/,
                      const double* __restrict__ casc_consts /*[FD_NC], PID mode*/, float* __restrict__ actions_out,
                      const S* __restrict__ rw_delta /*[3][n] or null*/,
-                     const double* __restrict__ pool, int pool_depth, uint64_t seed, int auto_reset,
+                     const double* __restrict__ pool, int pool_depth, uint64_t seed, int auto_reset, float residual_scale,
                      float* __restrict__ obs_out /*[n][18]*/, float* __restrict__ reward_f32, S* __restrict__ reward_full,
                      uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
                      int32_t* __restrict__ ev_count, int32_t* __restrict__ ev_count_next, int32_t* __restrict__ ev_int,
@@ -419,7 +419,10 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
     __shared__ float s_pid_cfg[3 * FD_NPC];
     __shared__ S s_consts[FD_NC];
     stage(s_params, params, n_types * FD_NP);
-    const bool pid_mode = actions == nullptr;
+    // actions == null: the fused rate-PID demonstrator drives the env.  residual_scale > 0 (with actions AND pid state):
+    // ResidualRateControlEnv -- action = clip(PID + scale * residual) (residual_rate_env.py:99-157).
+    const bool residual_mode = actions != nullptr && residual_scale > 0.0f && pid_state != nullptr;
+    const bool pid_mode = actions == nullptr || residual_mode;
     if (pid_mode) {
         stage(s_pid_cfg, pid_cfg, 3 * FD_NPC);
         for (int k = threadIdx.x; k < FD_NC; k += blockDim.x) s_consts[k] = S(casc_consts[k]);
@@ -457,6 +460,7 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
 
         // ---- action: from the policy ([n][4] f32, one 16-B load per lane) or the fused rate PID -------------
         float a_in[4];
+        S res_bonus = S(0);
         if (!pid_mode) {
             const float4 av = reinterpret_cast<const float4*>(actions)[i];
             a_in[0] = av.x; a_in[1] = av.y; a_in[2] = av.z; a_in[3] = av.w;
@@ -473,6 +477,19 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
             for (int k = 0; k < 3; ++k) {
                 pid_state[(k * FD_NPS + 0) * n + i] = st[k].integral; pid_state[(k * FD_NPS + 1) * n + i] = st[k].err_prev;
                 pid_state[(k * FD_NPS + 2) * n + i] = st[k].dfilt;
+            }
+            if (residual_mode) {                      // float32 arithmetic, as the reference's NumPy float32 arrays
+#pragma clang fp contract(off)
+                const float4 rv = reinterpret_cast<const float4*>(actions)[i];
+                const float rr[4] = { rv.x, rv.y, rv.z, rv.w };
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float c = a_in[k] + rr[k] * residual_scale;
+                    const float lo = k < 3 ? -1.0f : 0.0f;
+                    a_in[k] = c < lo ? lo : (c > 1.0f ? 1.0f : c);
+                }
+                const float mag = rr[0] * rr[0] + (rr[1] * rr[1] + rr[2] * rr[2]);
+                res_bonus = S(0.05) * (S(1) - S(mag) / S(3));   // small-correction bonus (:153-154); fp32 magnitude only
             }
         }
         if (actions_out) reinterpret_cast<float4*>(actions_out)[i] = make_float4(a_in[0], a_in[1], a_in[2], a_in[3]);
@@ -532,6 +549,7 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
                (airspeed < S(8));
         const bool trunc = step >= ec.max_steps;
         if (term && !trunc) reward += S(-100);                                    // :289-292
+        reward += res_bonus;
         e.ep_return += reward;
         done = term || trunc;
         env_observation<S>(x, e, airspeed, altitude, o);
@@ -724,20 +742,22 @@ FD_DEFINE_CASCADE(fdyn_cascade_step_f32, float, float)
                                     int n_types, const double* env_consts, const float* actions,             \
                                     float* pid_state, const float* pid_cfg, const double* casc_consts,       \
                                     float* actions_out, const S* rw_delta, const double* pool, int pool_depth, \
-                                    uint64_t seed, int auto_reset, float* obs_out, float* reward_f32,        \
+                                    uint64_t seed, int auto_reset, float residual_scale, float* obs_out,     \
+                                    float* reward_f32,                                                       \
                                     S* reward_full, uint8_t* terminated, uint8_t* truncated,                 \
                                     int32_t* ev_count, int32_t* ev_count_next, int32_t* ev_int,              \
                                     float* ev_flt, int ev_cap, int64_t n, void* stream)                      \
     {                                                                                                        \
         FD_CHECK_COMMON(n, n_types)                                                                          \
         if (pool && pool_depth < 1) return FDYN_ERR_BAD_SIZE;                                                \
-        if (!actions && !(pid_state && pid_cfg && casc_consts)) return FDYN_ERR_NULL;                        \
+        if ((!actions || residual_scale > 0.0f) && !(pid_state && pid_cfg && casc_consts)) return FDYN_ERR_NULL; \
         if (!obs_out || !terminated || !truncated || !env_consts) return FDYN_ERR_NULL;                      \
         if (ev_count && (!ev_int || !ev_flt || ev_cap < 0)) return FDYN_ERR_NULL;                            \
         const int lpw = pick_lpw(n);                                                                         \
         hipLaunchKernelGGL((rate_env_step_kernel<S, T>), dim3(grid_lpw(n, lpw)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
                            x, e, ei, type, params, n_types, env_consts, actions, pid_state, pid_cfg,         \
-                           casc_consts, actions_out, rw_delta, pool, pool_depth, seed, auto_reset, obs_out,  \
+                           casc_consts, actions_out, rw_delta, pool, pool_depth, seed, auto_reset,           \
+                           residual_scale, obs_out,                                                          \
                            reward_f32, reward_full, terminated, truncated, ev_count, ev_count_next, ev_int, ev_flt,  \
                            ev_cap, n, lpw);                                                                  \
         return launch_status();                                                                              \

@@ -26,7 +26,7 @@ class GpuRateVecEnv:
                  command_type: str = "step", seed: Optional[int] = None, precision: str = "mixed",
                  sampling: str = "device", pool_depth: int = 8, types: Sequence = ("rc_plane",),
                  type_index: Optional[np.ndarray] = None, event_capacity: Optional[int] = None,
-                 numpy_io: bool = False, device=None):
+                 numpy_io: bool = False, device=None, residual_scale: float = 0.0):
         self.lib = _lib.load()
         self.device = device or _lib.require_gpu()
         self.num_envs = self.n = int(num_envs)
@@ -34,6 +34,8 @@ class GpuRateVecEnv:
         self.difficulty, self.episode_length, self.dt, self.command_type = difficulty, episode_length, dt, command_type
         self.seed_value = 0 if seed is None else int(seed)
         self.numpy_io = numpy_io
+        # > 0: ResidualRateControlEnv semantics (residual_rate_env.py:17-182): actions are corrections added to the fused PID
+        self.residual_scale = float(residual_scale)
         dev, n = self.device, self.n
         self.env_consts_host = env_consts(difficulty, episode_length, dt, command_type)
         self.env_consts = torch.as_tensor(self.env_consts_host, device=dev)
@@ -95,7 +97,7 @@ class GpuRateVecEnv:
                            _lib.ptr(self.params), self.n_types, _lib.ptr(self.env_consts), _lib.ptr(actions),
                            _lib.ptr(self.pid_state), _lib.ptr(self.pid_cfg), _lib.ptr(self.casc_consts),
                            _lib.ptr(self.actions_taken), _lib.ptr(rw_delta), _lib.ptr(self.pool), self.pool_depth,
-                           self.seed_value, int(auto_reset), _lib.ptr(self.obs), _lib.ptr(self.rewards),
+                           self.seed_value, int(auto_reset), self.residual_scale, _lib.ptr(self.obs), _lib.ptr(self.rewards),
                            _lib.ptr(self.rewards_full), _lib.ptr(self.terminated), _lib.ptr(self.truncated),
                            cur.data_ptr(), nxt.data_ptr(), _lib.ptr(self.ev_int), _lib.ptr(self.ev_flt), self.ev_cap,
                            self.n, _lib.current_stream())

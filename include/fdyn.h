@@ -96,6 +96,8 @@ int fdyn_cascade_step_f32(float* x, float* pid_state, int32_t* wp_idx, const uin
  * step : actions [n][4] fp32 (aileron, elevator, rudder, throttle), or NULL => the fused rate-PID demonstrator
  *        (needs pid_state, pid_cfg [>=3][FD_NPC], casc_consts [FD_NC]); actions_out [n][4] or NULL
  *        rw_delta [3][n] this step's random-walk deltas (parity mode) or NULL
+ *        residual_scale > 0 (with actions, pid_state, pid_cfg, casc_consts): ResidualRateControlEnv
+ *        (learned_controllers/envs/residual_rate_env.py:99-157): action = clip(PID + scale * actions), reward += bonus
  *        auto_reset != 0: envs that end are reset in-kernel and obs_out holds the post-reset observation
  *        reward_f32 [n] / reward_full [n] (either may be NULL) ; terminated, truncated [n] uint8
  *        ev_count [1] int32 (must be 0 on entry), ev_int [ev_cap][FD_EV_NI], ev_flt [ev_cap][FD_EV_NF]: compacted
@@ -110,7 +112,8 @@ int fdyn_cascade_step_f32(float* x, float* pid_state, int32_t* wp_idx, const uin
                                     int n_types, const double* env_consts, const float* actions,                \
                                     float* pid_state, const float* pid_cfg, const double* casc_consts,          \
                                     float* actions_out, const S* rw_delta, const double* pool, int pool_depth,  \
-                                    uint64_t seed, int auto_reset, float* obs_out, float* reward_f32,           \
+                                    uint64_t seed, int auto_reset, float residual_scale, float* obs_out,        \
+                                    float* reward_f32,                                                          \
                                     S* reward_full, uint8_t* terminated, uint8_t* truncated,                    \
                                     int32_t* ev_count, int32_t* ev_count_next, int32_t* ev_int,                 \
                                     float* ev_flt, int ev_cap, int64_t n, void* stream);

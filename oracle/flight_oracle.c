@@ -529,6 +529,29 @@ void orc_env_step(const double *P, const double *EC, double x[FD_NX], double e[F
     *reward = r; *terminated = term; *truncated = trunc;
 }
 
+void orc_residual_env_step(const double *P, const double *EC, const float *pid_cfg, float *pid_state, const double *C,
+                           double x[FD_NX], double e[FD_NE], int32_t ei[FD_NEI], const float residual[FD_ACT_DIM],
+                           float scale, const double rw_delta[3], float obs[FD_OBS_DIM], double *reward,
+                           int32_t *terminated, int32_t *truncated, float pid_action_out[FD_ACT_DIM])
+{   /* learned_controllers/envs/residual_rate_env.py:99-157 (float32 action arithmetic as NumPy does it) */
+    const double cmd[3] = { e[FD_E_CMD_P], e[FD_E_CMD_Q], e[FD_E_CMD_R] };
+    double surf[FD_NU];
+    orc_rate_agent(pid_cfg, pid_state, C, cmd, 0.6, x, EC[FD_EC_DT], surf);
+    const float pid_a[4] = { (float)surf[FD_U_AILERON], (float)surf[FD_U_ELEVATOR], (float)surf[FD_U_RUDDER], (float)surf[FD_U_THROTTLE] };
+    float comb[4];
+    for (int i = 0; i < 4; ++i) {
+        const float c = pid_a[i] + residual[i] * scale;
+        const float lo = i < 3 ? -1.0f : 0.0f;
+        comb[i] = c < lo ? lo : (c > 1.0f ? 1.0f : c);
+        if (pid_action_out) pid_action_out[i] = pid_a[i];
+    }
+    orc_env_step(P, EC, x, e, ei, comb, rw_delta, obs, reward, terminated, truncated);
+    const float mag = residual[0] * residual[0] + (residual[1] * residual[1] + residual[2] * residual[2]);
+    const double bonus = 0.05 * (1.0 - (double)mag / 3.0);   /* numpy<2: float32 scalar / python float -> float64 */
+    *reward += bonus;
+    e[FD_E_EP_RETURN] += bonus;
+}
+
 /* ---------- batch drivers (SoA) -------------------------------------------------------------------------- */
 int orc_max_threads(void)
 {

@@ -40,6 +40,7 @@ def _load():
         "orc_settle_bonus": (C.c_double, [_d, _d, _d, C.c_double]),
         "orc_env_reset": (None, [_d, _d, _d, _i, _d, _f]),
         "orc_env_step": (None, [_d, _d, _d, _d, _i, _f, _d, _f, _d, _i, _i]),
+        "orc_residual_env_step": (None, [_d, _d, _f, _f, _d, _d, _d, _i, _f, C.c_float, _d, _f, _d, _i, _i, _f]),
         "orc_sixdof_step_batch": (None, [_d, _d, _d, C.c_int64, C.c_double, C.c_int, C.c_int]),
         "orc_env_step_batch": (None, [_d, _d, _d, _d, _i, _f, _f, _d, _i, _i, C.c_int64, C.c_int]),
         "orc_cascade_step_batch": (None, [_d, _f, _f, _d, _d, C.c_int, _i, _d, _d, C.c_int64, C.c_double,

@@ -610,6 +610,31 @@ def gen_env():
                 d[f"ep{j}_{k_}"] = v
         save(f"env_{diff}_{ct}_seed{seed}_pid.npz", **d)
 
+    # residual env (residual_rate_env.py:99-157) composed over the same reference objects: PID + 0.3 * residual
+    env = RefComposedRateEnv(difficulty="medium", command_type="step", rng_seed=17)
+    obs = [env.reset(seed=17)]
+    pid = RateAgent(ControllerConfig())
+    res = np.clip(np.random.RandomState(23).normal(0, 0.4, (500, 4)), -1, 1).astype(np.float32)   # own stream: later fixtures keep theirs
+    scale = 0.3
+    rews, flags, pid_acts, comb_acts = [], [], [], []
+    for k in range(500):
+        c = ControlCommand(mode=ControlMode.RATE, roll_rate=env.rate_command[0], pitch_rate=env.rate_command[1],
+                           yaw_rate=env.rate_command[2], throttle=0.6)
+        s = pid.compute_action(c, env.sim.get_state(), dt=env.dt)
+        pa = np.array([s.aileron, s.elevator, s.rudder, s.throttle], dtype=np.float32)
+        comb = pa + res[k] * scale
+        comb[:3] = np.clip(comb[:3], -1.0, 1.0)
+        comb[3] = np.clip(comb[3], 0.0, 1.0)
+        o, r, term, trunc, settled = env.step(comb)
+        # the reference pins numpy<2 (requirements.txt:5): float32 scalar / python float -> float64 there, so only the
+        # magnitude is float32; spelled out so NumPy 2's weak-scalar promotion does not round the reward to float32
+        r = float(r) + 0.05 * (1.0 - float(np.sum(res[k][:3] ** 2)) / 3.0)
+        obs.append(o); rews.append(float(r)); flags.append([term, trunc]); pid_acts.append(pa); comb_acts.append(comb.copy())
+        if term or trunc:
+            break
+    save("env_residual_medium_step_seed17.npz", obs=np.array(obs), residual=res[:len(rews)], rewards=np.array(rews),
+         flags=np.array(flags), pid_actions=np.array(pid_acts), combined=np.array(comb_acts), scale=scale)
+
     # reward / settle unit sequences (rewards.py:48-137,168-221)
     T = 300
     errs = rs.normal(0, 0.2, (T, 3)) * np.exp(-np.arange(T) / 80.0)[:, None]

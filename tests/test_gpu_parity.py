@@ -354,3 +354,18 @@ def test_cascade_full_size_replication_property():
     assert bool((c.x == c.x[:, 0:1]).all()) and bool((c.pid_state == c.pid_state[:, 0:1]).all())
     assert bool((c.wp_idx == c.wp_idx[0]).all())
     assert rel_err(c.state_numpy()[0], g["traj"][50], STATE_ANGLE_COLS).max() < 1e-3   # closed loop, mixed precision
+
+
+def test_residual_env_f64_vs_fixture():
+    """ResidualRateControlEnv semantics in the fused kernel: action = clip(PID + 0.3 residual), reward bonus."""
+    g = load_golden("env_residual_medium_step_seed17.npz")
+    env = GpuRateVecEnv(1, "medium", 10.0, 0.02, "step", seed=17, precision="f64", sampling="parity", pool_depth=2,
+                        residual_scale=float(g["scale"]))
+    obs0 = env.reset().cpu().numpy()[0]
+    assert rel_err(obs0, g["obs"][0]).max() < 1e-6
+    for k in range(len(g["rewards"])):
+        env.step(torch.as_tensor(g["residual"][k:k + 1]), auto_reset=False)
+        assert np.abs(env.actions_taken.cpu().numpy()[0] - g["combined"][k]).max() < 2e-6, k
+        assert abs(float(env.rewards_full[0]) - g["rewards"][k]) < 1e-6, k
+        assert int(env.terminated[0]) == int(g["flags"][k, 0]) and int(env.truncated[0]) == int(g["flags"][k, 1])
+        assert rel_err(env.obs.cpu().numpy()[0], g["obs"][k + 1]).max() < 1e-6, k

@@ -316,3 +316,29 @@ def test_env_episodes(oracle, name, diff, ct, seed):
         assert np.abs(ep["rewards"] - g[pre + "rewards"]).max() < 1e-7
         assert rel_err(ep["obs"], g[pre + "obs"]).max() < 1e-6
         assert rel_err(ep["states"], g[pre + "states"], STATE_ANGLE_COLS).max() < 1e-8
+
+
+def test_residual_env_episode(oracle):
+    """ResidualRateControlEnv (PID + 0.3 x residual, small-correction bonus): residual_rate_env.py:99-157."""
+    g = load_golden("env_residual_medium_step_seed17.npz")
+    P = AircraftParams().to_block()
+    EC = samplers.env_consts("medium", 10.0, 0.02, "step")
+    st = samplers.EpisodeStreams("medium", "step", 17)
+    st.reseed_env_rng(17)
+    pc, Cc = _tables(False)
+    ps = np.zeros((L.FD_NPID, L.FD_NPS), np.float32)
+    x, e, ei = np.zeros(12), np.zeros(L.FD_NE), np.zeros(L.FD_NEI, np.int32)
+    obs = np.zeros(18, np.float32)
+    oracle.lib.orc_env_reset(oracle.dp(EC), oracle.dp(x), oracle.dp(e), oracle.ip(ei), oracle.dp(st.next_record()), oracle.fp(obs))
+    assert rel_err(obs, g["obs"][0]).max() < 1e-6
+    r, te, tr = np.zeros(1), np.zeros(1, np.int32), np.zeros(1, np.int32)
+    pa = np.zeros(4, np.float32)
+    for k in range(len(g["rewards"])):
+        oracle.lib.orc_residual_env_step(oracle.dp(P), oracle.dp(EC), oracle.fp(pc), oracle.fp(ps), oracle.dp(Cc), oracle.dp(x),
+                                         oracle.dp(e), oracle.ip(ei), oracle.fp(np.ascontiguousarray(g["residual"][k])),
+                                         float(g["scale"]), oracle.dp(np.zeros(3)), oracle.fp(obs), oracle.dp(r), oracle.ip(te),
+                                         oracle.ip(tr), oracle.fp(pa))
+        assert np.abs(pa - g["pid_actions"][k]).max() < 2e-6, k
+        assert abs(r[0] - g["rewards"][k]) < 1e-6, k
+        assert (te[0], tr[0]) == tuple(int(v) for v in g["flags"][k])
+        assert rel_err(obs, g["obs"][k + 1]).max() < 1e-6, k
