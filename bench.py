@@ -136,10 +136,16 @@ class Workload:
 
     @torch.no_grad()
     def _rollout_step(self):
+        """One policy + env step with every buffer updated in place (capture-safe)."""
         p = self.ppo
-        a, _v, _lp, p.states = p.policy.step(p.obs, p.states, p.episode_start)
-        obs, _r, term, trunc = self.env.step_device(a)
-        p.obs, p.episode_start = obs, (term | trunc).float()
+        nxt = p._state_bufs[1 - p._cur]
+        a, _v, _lp, new_states = p.policy.step(p.obs, p.states, p.episode_start, out_states=nxt)
+        _obs, _r, term, trunc = self.env.step_device(a)          # p.obs aliases the env's observation buffer
+        for dst, src in zip(nxt, new_states):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
+        p._cur = 1 - p._cur
+        p.episode_start.copy_((term | trunc).float())
 
     def step(self, k):
         if self.kind == "rollout":
@@ -162,7 +168,7 @@ def timed_region(wl, args, world):
     K, W = args.steps, args.warmup
     stream = torch.cuda.current_stream()
     graph, gsteps = None, 0
-    if args.graph and K >= 2 and args.workload in ("env", "env_pid", "physics", "cascade"):
+    if args.graph and K >= 2 and args.workload in ("env", "env_pid", "physics", "cascade", "rollout"):
         gsteps = max(2, min(args.graph_steps, K) // 2 * 2)          # even: the event counters ping-pong
         side = torch.cuda.Stream()
         side.wait_stream(stream)

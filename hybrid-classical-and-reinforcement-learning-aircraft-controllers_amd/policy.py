@@ -148,7 +148,7 @@ class RateLSTMPolicy(nn.Module):
             """[(w_bf16, b_bf16), ...] of the Linear layers of a Sequential (ReLU follows each one)."""
             return [(m.weight.detach().to(bf).contiguous(), m.bias.detach().to(bf).contiguous())
                     for m in seq if isinstance(m, nn.Linear)]
-        self._inf = {
+        new = {
             "fe_w": [getattr(fe.lstm, f"weight_ih_l{k}").detach().to(bf).contiguous() for k in range(fe.lstm.num_layers)],
             "fe_b": [bias(fe.lstm, k) for k in range(fe.lstm.num_layers)],
             "pi_w": cat(self.lstm_actor, 0), "pi_b": bias(self.lstm_actor, 0),
@@ -158,6 +158,19 @@ class RateLSTMPolicy(nn.Module):
             "emb": lin(fe.embedding), "proj": lin(fe.output_proj), "pi": lin(self.pi_net), "vf": lin(self.vf_net),
             "act": lin([self.action_net])[0], "val": lin([self.value_net])[0],
         }
+        old = getattr(self, "_inf", None)
+        if old is None:
+            self._inf = new
+        else:       # refresh IN PLACE: a captured rollout graph holds these pointers
+
+            def refresh(dst, src):
+                if isinstance(dst, torch.Tensor):
+                    dst.copy_(src)
+                else:
+                    for d_, s_ in zip(dst, src):
+                        refresh(d_, s_)
+            for k in new:
+                refresh(old[k], new[k])
 
     @staticmethod
     def _mlp_bf16(x, layers):
@@ -170,7 +183,7 @@ class RateLSTMPolicy(nn.Module):
         return (inf is not None and obs.is_cuda and self.compute_dtype == torch.bfloat16 and not torch.is_grad_enabled()
                 and self.hidden == 256 and all(w.shape[1] in (128, 256) for w in inf["fe_w"]))
 
-    def _core_fused(self, obs, states: RNNStates, keep):
+    def _core_fused(self, obs, states: RNNStates, keep, out_states: Optional[RNNStates] = None):
         """Explicit bf16 inference path (no autocast): pre-cast Linear weights + one MFMA kernel per LSTM cell."""
         from . import _lib
         lib, inf, B, H = _lib.load(), self._inf, obs.shape[0], self.hidden
@@ -188,11 +201,17 @@ class RateLSTMPolicy(nn.Module):
             x = h
         feats = self._mlp_bf16(x, inf["proj"])
         out = []
-        for w, b, hp, cp in ((inf["pi_w"], inf["pi_b"], states.pi_h, states.pi_c), (inf["vf_w"], inf["vf_b"], states.vf_h, states.vf_c)):
+        outs = (None, None, None, None) if out_states is None else tuple(out_states)
+        for (w, b, hp, cp), (ho, co) in zip(((inf["pi_w"], inf["pi_b"], states.pi_h, states.pi_c),
+                                             (inf["vf_w"], inf["vf_b"], states.vf_h, states.vf_c)), (outs[0:2], outs[2:4])):
             hp, cp = hp.to(bf).contiguous(), cp.float().contiguous()
             assert shapes_ok(feats, w, b, H) and hp.shape == (B, H) and cp.shape == (B, H) and keep.shape == (B,) \
                 and w.shape[0] == 4 * H, "lstm_cell_mfma operand shapes"
-            h, c = torch.empty((B, H), dtype=bf, device=dev), torch.empty((B, H), dtype=torch.float32, device=dev)
+            # the kernel writes the new state straight into the caller's ping-pong buffers when given (no copies)
+            ok = ho is not None and ho.dtype == bf and ho.shape == (B, H) and ho.is_contiguous() and co.dtype == torch.float32 \
+                and co.shape == (B, H) and co.is_contiguous() and ho.data_ptr() != hp.data_ptr() and co.data_ptr() != cp.data_ptr()
+            h = ho if ok else torch.empty((B, H), dtype=bf, device=dev)
+            c = co if ok else torch.empty((B, H), dtype=torch.float32, device=dev)
             _lib.check(lib.fdyn_lstm_cell_mfma(feats.data_ptr(), feats.shape[1], hp.data_ptr(), H, cp.data_ptr(),
                                                keep.data_ptr(), w.data_ptr(), b.data_ptr(), h.data_ptr(), c.data_ptr(), None,
                                                B, H, st), "lstm_cell_mfma")
@@ -201,11 +220,12 @@ class RateLSTMPolicy(nn.Module):
         value = F.linear(self._mlp_bf16(out[2], inf["vf"]), *inf["val"]).float().squeeze(-1)
         return mean, value, RNNStates(*out)
 
-    def step(self, obs, states: RNNStates, episode_start, deterministic: bool = False):
+    def step(self, obs, states: RNNStates, episode_start, deterministic: bool = False,
+             out_states: Optional[RNNStates] = None):
         """obs [B,18], episode_start [B] (1 where the env was just reset) -> actions, values, log_probs, new states."""
         if self._fused_ok(obs):
             keep = (1.0 - episode_start.float()).contiguous()            # the mask is applied inside the kernel
-            mean, value, new_states = self._core_fused(obs, states, keep)
+            mean, value, new_states = self._core_fused(obs, states, keep, out_states)
             std = self.log_std.exp()
             actions = mean if deterministic else mean + std * torch.randn_like(mean)
             return actions, value, self._log_prob(actions, mean), new_states

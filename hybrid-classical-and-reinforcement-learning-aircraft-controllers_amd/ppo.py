@@ -102,8 +102,10 @@ def compute_gae(rewards, values, episode_starts, last_values, last_dones, gamma,
 
 
 class RecurrentPPO:
-    def __init__(self, env, policy: Optional[RateLSTMPolicy] = None, config: Optional[PPOConfig] = None, seed: int = 0):
+    def __init__(self, env, policy: Optional[RateLSTMPolicy] = None, config: Optional[PPOConfig] = None, seed: int = 0,
+                 use_graph: bool = True):
         self.env, self.cfg = env, config or PPOConfig()
+        self.use_graph, self._graph, self._graph_env = use_graph, None, None
         self.device = env.device
         torch.manual_seed(seed)                          # identical initial weights on every rank
         self.policy = (policy or RateLSTMPolicy()).to(self.device)
@@ -117,47 +119,86 @@ class RecurrentPPO:
         self.buf_obs = torch.zeros((T, N, 18), **f32)
         self.buf_act = torch.zeros((T, N, 4), **f32)
         self.buf_rew, self.buf_val, self.buf_logp, self.buf_start = (torch.zeros((T, N), **f32) for _ in range(4))
-        self.obs = env.reset().clone()
-        self.states = self.policy.initial_state(N, self.device)
+        self.obs = env.reset()                           # aliases the env's observation buffer (rewritten every step)
+        self._alloc_states(N)
         self.episode_start = torch.ones(N, **f32)
         self.num_timesteps = 0
         self.ep_returns, self.ep_lengths = [], []
         self.last_stats = {}
 
+    def _alloc_states(self, n):
+        """Fixed recurrent-state buffers: h in the policy's compute dtype (what the MFMA cell emits), c in fp32."""
+        pol = self.policy
+        hd = pol.compute_dtype if (pol.compute_dtype is not None and self.device.type == "cuda") else torch.float32
+        z = lambda dt: torch.zeros(n, pol.hidden, dtype=dt, device=self.device)  # noqa: E731
+        mk = lambda: RNNStates(z(hd), z(torch.float32), z(hd), z(torch.float32))  # noqa: E731
+        self._state_bufs, self._cur = [mk(), mk()], 0        # ping-pong: step t reads one set and writes the other
+        self.rollout_states = mk()
+
+    @property
+    def states(self) -> RNNStates:
+        return self._state_bufs[self._cur]
+
     def set_env(self, env):
         """Curriculum phases swap the env (train_rate.py:155-170); recurrent state and episode flags restart."""
         assert env.num_envs == self.env.num_envs
         self.env = env
-        self.obs = env.reset().clone()
-        self.states = self.policy.initial_state(env.num_envs, self.device)
-        self.episode_start = torch.ones(env.num_envs, dtype=torch.float32, device=self.device)
+        self.obs = env.reset()
+        for t in self.states:
+            t.zero_()
+        self.episode_start.fill_(1.0)
 
-    @torch.no_grad()
-    def collect_rollout(self):
+    def _rollout_body(self):
+        """T policy+env steps, device ops only (no host sync): runs eagerly or under hipGraph capture.  All state lives in
+        fixed buffers (self.obs / self.states / self.episode_start are updated IN PLACE) so a captured graph can be replayed."""
         env, pol, cfg = self.env, self.policy, self.cfg
-        pol.prepare_inference()                           # bf16 weight snapshot for the fused MFMA rollout path
-        self.rollout_states = self.states
-        ev_r, ev_l = [], []
+        for dst, src in zip(self.rollout_states, self.states):
+            dst.copy_(src)
         for t in range(cfg.n_steps):
-            actions, values, logp, new_states = pol.step(self.obs, self.states, self.episode_start)
-            self.buf_obs[t], self.buf_act[t], self.buf_val[t], self.buf_logp[t], self.buf_start[t] = (
-                self.obs, actions, values, logp, self.episode_start)
+            nxt = self._state_bufs[1 - self._cur]             # the fused cells write the new state straight into it
+            actions, values, logp, new_states = pol.step(self.obs, self.states, self.episode_start, out_states=nxt)
+            self.buf_obs[t].copy_(self.obs); self.buf_act[t].copy_(actions); self.buf_val[t].copy_(values)
+            self.buf_logp[t].copy_(logp); self.buf_start[t].copy_(self.episode_start)
             obs, rew, term, trunc = env.step_device(actions)          # clip happens in-kernel (rate_env.py:225)
-            done = (term | trunc).float()
-            self.buf_rew[t] = rew
+            self.buf_rew[t].copy_(rew)
             if cfg.bootstrap_timeouts:
                 # time-limit truncation is not failure: add gamma * V(s_T) (vec-env 'TimeLimit.truncated' handling).
                 # The post-step critic state belongs to the finished episode, so it can value the terminal observation.
-                ints, flts = env.episode_events()
+                ints, flts = env.episode_events()                     # host sync: this option disables graph replay
                 if ints.shape[0]:
                     tr = ints[:, 2] == 0
                     if bool(tr.any()):
                         ids = ints[tr, 0].long()
                         v = pol.predict_values(flts[tr, 1:], new_states.index(ids), torch.zeros(ids.numel(), device=self.device))
                         self.buf_rew[t, ids] += cfg.gamma * v
-            self.obs = obs.clone()
-            self.states, self.episode_start = new_states, done
-        self.num_timesteps += cfg.n_steps * env.num_envs
+            if obs.data_ptr() != self.obs.data_ptr():
+                self.obs.copy_(obs)                               # (self.obs aliases the env's observation buffer on the GPU)
+            for dst, src in zip(nxt, new_states):
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src)                                # un-fused policy paths return fresh tensors
+            self._cur = 1 - self._cur
+            self.episode_start.copy_((term | trunc).float())
+
+    @torch.no_grad()
+    def collect_rollout(self):
+        pol, cfg = self.policy, self.cfg
+        pol.prepare_inference()                           # bf16 weight snapshot (refreshed IN PLACE) for the fused MFMA path
+        if self.use_graph and not cfg.bootstrap_timeouts and self.device.type == "cuda" and cfg.n_steps % 2 == 0:
+            if self._graph is None or self._graph_env is not self.env:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    self._rollout_body()                  # warm-up on a side stream (allocator, lazy init) -- a real rollout
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                self._graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph):
+                    self._rollout_body()
+                self._graph_env = self.env
+            self._graph.replay()                          # the whole T-step rollout is ONE graph launch
+        else:
+            self._rollout_body()
+        self.num_timesteps += cfg.n_steps * self.env.num_envs
         last_values = pol.predict_values(self.obs, self.states, self.episode_start)
         self.adv, self.ret = compute_gae(self.buf_rew, self.buf_val, self.buf_start, last_values, self.episode_start,
                                          cfg.gamma, cfg.gae_lambda)
