@@ -150,6 +150,61 @@ gae_kernel(const float* __restrict__ rew, const float* __restrict__ val, const f
     }
 }
 
+// Diagonal-Gaussian action sampling + log-probability for a [B][4] mean (the policy head of the rate controller):
+// actions = mean + exp(log_std) * N(0,1), log_prob = sum_k -0.5 z_k^2 - log_std_k - 0.5 log(2 pi).  One lane per env, one
+// 16-byte load and store; the normals come from Philox-4x32-10 keyed by (seed, env, *step) (Box-Muller), where the step counter
+// is a word in DEVICE memory that the caller bumps on the stream -- so a captured graph draws fresh noise on every replay.
+// Replaces a dozen tiny element-wise / reduction launches per policy step.
+__device__ __forceinline__ void philox4(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t (&o)[4])
+{
+    uint32_t k0 = uint32_t(seed), k1 = uint32_t(seed >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = uint64_t(0xD2511F53u) * c0, p1 = uint64_t(0xCD9E8D57u) * c2;
+        const uint32_t n0 = uint32_t(p1 >> 32) ^ c1 ^ k0, n2 = uint32_t(p0 >> 32) ^ c3 ^ k1;
+        c1 = uint32_t(p1); c3 = uint32_t(p0); c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+template <typename MT>
+__global__ void __launch_bounds__(256)
+gaussian_head_kernel(const MT* __restrict__ mean /*[B][4]*/, const float* __restrict__ log_std /*[4]*/, uint64_t seed,
+                     const uint32_t* __restrict__ step_ptr, int deterministic, float* __restrict__ actions /*[B][4]*/, float* __restrict__ logp /*[B]*/,
+                     int64_t B)
+{
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    float m[4];
+    if constexpr (sizeof(MT) == 2) {
+        const uint2 v = reinterpret_cast<const uint2*>(mean)[i];
+        m[0] = __uint_as_float(v.x << 16); m[1] = __uint_as_float(v.x & 0xffff0000u);
+        m[2] = __uint_as_float(v.y << 16); m[3] = __uint_as_float(v.y & 0xffff0000u);
+    } else {
+        const float4 v = reinterpret_cast<const float4*>(mean)[i];
+        m[0] = v.x; m[1] = v.y; m[2] = v.z; m[3] = v.w;
+    }
+    float z[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    if (!deterministic) {
+        uint32_t r[4];
+        philox4(seed, uint32_t(i), uint32_t(i >> 32), step_ptr ? *step_ptr : 0u, 0x51u, r);
+        const float u0 = (float(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = (float(r[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float u2 = (float(r[2] >> 8) + 0.5f) * (1.0f / 16777216.0f), u3 = (float(r[3] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float ra = sqrtf(-2.0f * __logf(u0)), rb = sqrtf(-2.0f * __logf(u2));
+        z[0] = ra * __cosf(6.283185307f * u1); z[1] = ra * __sinf(6.283185307f * u1);
+        z[2] = rb * __cosf(6.283185307f * u3); z[3] = rb * __sinf(6.283185307f * u3);
+    }
+    float a[4], lp = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float ls = log_std[k];
+        a[k] = m[k] + __expf(ls) * z[k];
+        lp += -0.5f * z[k] * z[k] - ls - 0.9189385332046727f;
+    }
+    reinterpret_cast<float4*>(actions)[i] = make_float4(a[0], a[1], a[2], a[3]);
+    logp[i] = lp;
+}
+
 inline unsigned blocks(int64_t n) { return unsigned((n + 255) / 256); }
 
 }  // namespace
@@ -185,6 +240,21 @@ int fdyn_lstm_cell_bwd(const void* act, int bf16, const float* c_prev, const flo
     else
         hipLaunchKernelGGL((lstm_cell_bwd_kernel<float>), dim3(blocks(tv)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)act, c_prev, c_new, (const float*)dh, dc_next, (float*)dgates, dc_prev, tv, H);
+    return int(hipGetLastError());
+}
+
+int fdyn_gaussian_head(const void* mean, int mean_bf16, const float* log_std, uint64_t seed, const uint32_t* step, int deterministic,
+                       float* actions, float* logp, int64_t B, void* stream)
+{
+    if (B < 0) return FDYN_ERR_BAD_SIZE;
+    if (!mean || !log_std || !actions || !logp) return FDYN_ERR_NULL;
+    if (B == 0) return FDYN_OK;
+    if (mean_bf16)
+        hipLaunchKernelGGL((gaussian_head_kernel<uint16_t>), dim3(blocks(B)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)mean,
+                           log_std, seed, step, deterministic, actions, logp, B);
+    else
+        hipLaunchKernelGGL((gaussian_head_kernel<float>), dim3(blocks(B)), dim3(256), 0, (hipStream_t)stream, (const float*)mean,
+                           log_std, seed, step, deterministic, actions, logp, B);
     return int(hipGetLastError());
 }
 

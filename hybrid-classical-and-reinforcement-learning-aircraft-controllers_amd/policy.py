@@ -175,7 +175,7 @@ class RateLSTMPolicy(nn.Module):
     @staticmethod
     def _mlp_bf16(x, layers):
         for w, b in layers:
-            x = torch.relu_(F.linear(x, w, b))
+            x = torch._addmm_activation(b, x, w.t())        # relu(x W^T + b): bias + ReLU in the GEMM epilogue (hipBLASLt)
         return x
 
     def _fused_ok(self, obs):
@@ -216,7 +216,7 @@ class RateLSTMPolicy(nn.Module):
                                                keep.data_ptr(), w.data_ptr(), b.data_ptr(), h.data_ptr(), c.data_ptr(), None,
                                                B, H, st), "lstm_cell_mfma")
             out += [h, c]
-        mean = F.linear(self._mlp_bf16(out[0], inf["pi"]), *inf["act"]).float()
+        mean = F.linear(self._mlp_bf16(out[0], inf["pi"]), *inf["act"])                 # bf16 [B, 4]
         value = F.linear(self._mlp_bf16(out[2], inf["vf"]), *inf["val"]).float().squeeze(-1)
         return mean, value, RNNStates(*out)
 
@@ -226,9 +226,21 @@ class RateLSTMPolicy(nn.Module):
         if self._fused_ok(obs):
             keep = (1.0 - episode_start.float()).contiguous()            # the mask is applied inside the kernel
             mean, value, new_states = self._core_fused(obs, states, keep, out_states)
-            std = self.log_std.exp()
-            actions = mean if deterministic else mean + std * torch.randn_like(mean)
-            return actions, value, self._log_prob(actions, mean), new_states
+            # sampling + log-prob in one launch (in-kernel Philox keyed by a per-policy seed, the env index and a step counter
+            # that lives on the device so a captured graph draws fresh noise on every replay)
+            from . import _lib
+            B = mean.shape[0]
+            actions = torch.empty((B, ACT_DIM), dtype=torch.float32, device=mean.device)
+            logp = torch.empty(B, dtype=torch.float32, device=mean.device)
+            mean = mean.contiguous()
+            if not hasattr(self, "_noise_seed"):
+                self._noise_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+                self._noise_step = torch.zeros(1, dtype=torch.int32, device=mean.device)      # device-side step counter
+            self._noise_step.add_(1)
+            _lib.check(_lib.load().fdyn_gaussian_head(mean.data_ptr(), 1, self.log_std.detach().float().contiguous().data_ptr(),
+                                                      self._noise_seed, self._noise_step.data_ptr(), int(deterministic),
+                                                      actions.data_ptr(), logp.data_ptr(), B, _lib.current_stream()), "gaussian_head")
+            return actions, value, logp, new_states
         states = states.masked(1.0 - episode_start.float())
         with torch.autocast(obs.device.type, dtype=self.compute_dtype, enabled=self.compute_dtype is not None):
             lat_pi, lat_vf, new_states = self._core(obs, states)

@@ -142,6 +142,11 @@ int fdyn_lstm_cell_bwd(const void* act, int bf16, const float* c_prev, const flo
 int fdyn_lstm_cell_mfma(const void* x, int kx, const void* h_prev, int kh, const float* c_prev, const float* keep,
                         const void* W, const float* bias, void* h_out, float* c_out, float* h_out_f32,
                         int64_t B, int H, void* stream);
+/* Diagonal-Gaussian policy head: actions [B][4] = mean + exp(log_std) * N(0,1) (Philox keyed by seed, env, *step -- a
+ * uint32 counter in DEVICE memory the caller increments on the stream, so graph replays draw fresh noise; or the mean
+ * itself when deterministic), logp [B] = log-probability of the sampled action.  mean [B][4] bf16 (mean_bf16=1) or fp32. */
+int fdyn_gaussian_head(const void* mean, int mean_bf16, const float* log_std, uint64_t seed, const uint32_t* step, int deterministic,
+                       float* actions, float* logp, int64_t B, void* stream);
 /* GAE(lambda) over a [T][N] rollout (one lane per env): adv, ret [T][N].  episode_starts[t][n] = 1 if env n was reset
  * before step t; last_values / last_dones [N] describe the state after the final step.                              */
 int fdyn_gae(const float* rewards, const float* values, const float* episode_starts, const float* last_values,

@@ -176,3 +176,33 @@ def test_train_rate_cli_end_to_end(tmp_path):
     train_rate.main(["--config", str(p), "--bf16", "--bc-pretrain", "1"])
     ck = torch.load(tmp_path / "ckpt" / "final_model.pt", weights_only=True)
     assert ck["num_timesteps"] == 3 * 512 * 8 and "policy" in ck
+
+
+def test_gaussian_head_statistics_and_logprob():
+    """Fused sampling head: z = (a - mean)/std must be ~N(0,1), log_prob must equal the closed form, and two successive
+    calls (device-side step counter) must draw different noise."""
+    import math
+    from hcrl_amd import _lib
+    lib = _lib.load()
+    B = 200000
+    mean = torch.randn(B, 4, device="cuda").bfloat16()
+    log_std = torch.tensor([0.0, -0.5, 0.3, -1.0], device="cuda")
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    outs = []
+    for _ in range(2):
+        step.add_(1)
+        a = torch.empty(B, 4, device="cuda"); lp = torch.empty(B, device="cuda")
+        _lib.check(lib.fdyn_gaussian_head(mean.data_ptr(), 1, log_std.data_ptr(), 1234, step.data_ptr(), 0, a.data_ptr(),
+                                          lp.data_ptr(), B, _lib.current_stream()))
+        outs.append((a, lp))
+    a, lp = outs[0]
+    z = (a - mean.float()) / log_std.exp()
+    assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1.0) < 0.01
+    assert abs(float((z[:, 0] * z[:, 1]).mean())) < 0.01                       # Box-Muller pairs uncorrelated
+    ref = (-0.5 * z ** 2 - log_std - 0.5 * math.log(2 * math.pi)).sum(1)
+    assert (lp - ref).abs().max() < 1e-3
+    assert not torch.equal(outs[0][0], outs[1][0])
+    d = torch.empty(B, 4, device="cuda")
+    _lib.check(lib.fdyn_gaussian_head(mean.data_ptr(), 1, log_std.data_ptr(), 1234, step.data_ptr(), 1, d.data_ptr(),
+                                      lp.data_ptr(), B, _lib.current_stream()))
+    assert torch.equal(d, mean.float())
