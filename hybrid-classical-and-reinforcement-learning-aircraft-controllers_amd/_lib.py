@@ -36,6 +36,7 @@ SIGNATURES = {
     "fdyn_lstm_cell_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i64, _i, _p]),
     "fdyn_lstm_cell_mfma": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _p]),
     "fdyn_gaussian_head": (_i, [_p, _i, _p, _u64, _p, _i, _p, _p, _i64, _p]),
+    "fdyn_policy_heads": (_i, [_p, _p, _p, _p, _p, _p, _p, _u64, _p, _i, _p, _p, _p, _i64, _p]),
     "fdyn_gae": (_i, [_p, _p, _p, _p, _p, _f, _f, _i, _i64, _p, _p, _p]),
 }
 

@@ -216,30 +216,33 @@ class RateLSTMPolicy(nn.Module):
                                                keep.data_ptr(), w.data_ptr(), b.data_ptr(), h.data_ptr(), c.data_ptr(), None,
                                                B, H, st), "lstm_cell_mfma")
             out += [h, c]
-        mean = F.linear(self._mlp_bf16(out[0], inf["pi"]), *inf["act"])                 # bf16 [B, 4]
-        value = F.linear(self._mlp_bf16(out[2], inf["vf"]), *inf["val"]).float().squeeze(-1)
-        return mean, value, RNNStates(*out)
+        # the two trunks; the 64 -> 4 and 64 -> 1 output layers are fused with the sampling (fdyn_policy_heads)
+        return self._mlp_bf16(out[0], inf["pi"]), self._mlp_bf16(out[2], inf["vf"]), RNNStates(*out)
 
     def step(self, obs, states: RNNStates, episode_start, deterministic: bool = False,
              out_states: Optional[RNNStates] = None):
         """obs [B,18], episode_start [B] (1 where the env was just reset) -> actions, values, log_probs, new states."""
         if self._fused_ok(obs):
             keep = (1.0 - episode_start.float()).contiguous()            # the mask is applied inside the kernel
-            mean, value, new_states = self._core_fused(obs, states, keep, out_states)
-            # sampling + log-prob in one launch (in-kernel Philox keyed by a per-policy seed, the env index and a step counter
-            # that lives on the device so a captured graph draws fresh noise on every replay)
+            lat_pi, lat_vf, new_states = self._core_fused(obs, states, keep, out_states)
+            # output heads + sampling + log-prob in ONE launch (in-kernel Philox keyed by a per-policy seed, the env index
+            # and a step counter that lives on the device so a captured graph draws fresh noise on every replay)
             from . import _lib
-            B = mean.shape[0]
-            actions = torch.empty((B, ACT_DIM), dtype=torch.float32, device=mean.device)
-            logp = torch.empty(B, dtype=torch.float32, device=mean.device)
-            mean = mean.contiguous()
+            inf, B, dev = self._inf, obs.shape[0], obs.device
+            assert lat_pi.shape == (B, 64) and lat_vf.shape == (B, 64) and lat_pi.is_contiguous() and lat_vf.is_contiguous() \
+                and inf["act"][0].shape == (ACT_DIM, 64) and inf["val"][0].shape == (1, 64), "policy_heads operand shapes"
+            actions = torch.empty((B, ACT_DIM), dtype=torch.float32, device=dev)
+            logp = torch.empty(B, dtype=torch.float32, device=dev)
+            value = torch.empty(B, dtype=torch.float32, device=dev)
             if not hasattr(self, "_noise_seed"):
                 self._noise_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-                self._noise_step = torch.zeros(1, dtype=torch.int32, device=mean.device)      # device-side step counter
+                self._noise_step = torch.zeros(1, dtype=torch.int32, device=dev)      # device-side step counter
             self._noise_step.add_(1)
-            _lib.check(_lib.load().fdyn_gaussian_head(mean.data_ptr(), 1, self.log_std.detach().float().contiguous().data_ptr(),
-                                                      self._noise_seed, self._noise_step.data_ptr(), int(deterministic),
-                                                      actions.data_ptr(), logp.data_ptr(), B, _lib.current_stream()), "gaussian_head")
+            _lib.check(_lib.load().fdyn_policy_heads(lat_pi.data_ptr(), lat_vf.data_ptr(), inf["act"][0].data_ptr(),
+                                                     inf["act"][1].data_ptr(), inf["val"][0].data_ptr(), inf["val"][1].data_ptr(),
+                                                     self.log_std.detach().float().contiguous().data_ptr(), self._noise_seed,
+                                                     self._noise_step.data_ptr(), int(deterministic), actions.data_ptr(),
+                                                     logp.data_ptr(), value.data_ptr(), B, _lib.current_stream()), "policy_heads")
             return actions, value, logp, new_states
         states = states.masked(1.0 - episode_start.float())
         with torch.autocast(obs.device.type, dtype=self.compute_dtype, enabled=self.compute_dtype is not None):

@@ -147,6 +147,11 @@ int fdyn_lstm_cell_mfma(const void* x, int kx, const void* h_prev, int kh, const
  * itself when deterministic), logp [B] = log-probability of the sampled action.  mean [B][4] bf16 (mean_bf16=1) or fp32. */
 int fdyn_gaussian_head(const void* mean, int mean_bf16, const float* log_std, uint64_t seed, const uint32_t* step, int deterministic,
                        float* actions, float* logp, int64_t B, void* stream);
+/* Both output heads + sampling in one launch: mean = pi_hidden [B][64] Wa^T + ba (action_net 64 -> 4), value = vf_hidden
+ * [B][64] wv + bv (value_net 64 -> 1), then the Gaussian head.  All weights / hiddens bf16; actions [B][4], logp, value fp32. */
+int fdyn_policy_heads(const void* pi_hidden, const void* vf_hidden, const void* Wa, const void* ba, const void* wv, const void* bv,
+                      const float* log_std, uint64_t seed, const uint32_t* step, int deterministic, float* actions, float* logp,
+                      float* value, int64_t B, void* stream);
 /* GAE(lambda) over a [T][N] rollout (one lane per env): adv, ret [T][N].  episode_starts[t][n] = 1 if env n was reset
  * before step t; last_values / last_dones [N] describe the state after the final step.                              */
 int fdyn_gae(const float* rewards, const float* values, const float* episode_starts, const float* last_values,
