@@ -57,7 +57,7 @@ lstm_cell_mfma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const uin
                       const float* __restrict__ c_prev /*[B][H]*/, const float* __restrict__ keep /*[B] or null*/,
                       const uint16_t* __restrict__ W /*[4H][KX+KH] bf16*/, const float* __restrict__ bias /*[4H]*/,
                       uint16_t* __restrict__ h_out /*[B][H] bf16*/, float* __restrict__ c_out /*[B][H]*/,
-                      float* __restrict__ h_out_f32 /*[B][H] or null*/, int64_t B, int H)
+                      float* __restrict__ h_out_f32 /*[B][H] or null*/, int64_t B, int H, int split)
 {
     constexpr int K = KX + KH;
     constexpr int KSTEPS = K / 16;
@@ -81,7 +81,11 @@ lstm_cell_mfma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const uin
     const int64_t row0 = int64_t(blockIdx.x) * BM + wave * 32;
     const int64_t my_row = row0 + r;                      // A-operand row of this lane
     const bool row_ok = my_row < B;
-    const int n_slices = H / NSLICE;
+    // `split` workgroups share one 128-row block, each taking n_slices / split of the hidden slices (blockIdx.y): small
+    // batches (B / 128 < 2 x CUs) would otherwise leave most of the chip idle.  Costs one extra read of the row block's
+    // activation slab per split.
+    const int n_slices = (H / NSLICE) / split;
+    const int slice0 = int(blockIdx.y) * n_slices;
 
     // chunk (sl, pass, ch): 64 weight rows = gates (pass, pass + 2) of hidden units sl*32 .. +31, columns ch*KC .. +KC;
     // pass 0 = (i, g), pass 1 = (f, o).  Zero-state layers have no use for f: their pass 1 still stages (f, o) -- every
@@ -108,7 +112,7 @@ lstm_cell_mfma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const uin
     // the rotation mixes b and b / 8: the workgroups of one XCD then have 8 different slices in flight.  Speed only -- any
     // placement gives the same result.
     const int sl_start = int((blockIdx.x + (blockIdx.x >> 3)) % unsigned(n_slices));   // b%8 and b/8 both rotate (measured best)
-#define FD_SL(I) (((I) + sl_start) % n_slices)
+#define FD_SL(I) (slice0 + ((I) + sl_start) % n_slices)
     FD_FETCH(FD_SL(0), 0, 0)                              // start the weight stream before the activation slab
 
     // ---- A slab -> registers (masked h part).  Branch-free: rows past B read row B-1 (their results are never stored) and
@@ -221,8 +225,17 @@ template <int KX, int KH>
 int launch(const void* x, const void* h_prev, const float* c_prev, const float* keep, const void* W, const float* bias,
            void* h_out, float* c_out, float* h_out_f32, int64_t B, int H, hipStream_t st)
 {
-    hipLaunchKernelGGL((lstm_cell_mfma_kernel<KX, KH>), dim3(unsigned((B + BM - 1) / BM)), dim3(256), 0, st, (const uint16_t*)x,
-                       (const uint16_t*)h_prev, c_prev, keep, (const uint16_t*)W, bias, (uint16_t*)h_out, c_out, h_out_f32, B, H);
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0; hipDeviceProp_t p;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
+    }
+    const int64_t row_blocks = (B + BM - 1) / BM;
+    int split = 1;                                        // aim for >= 2 workgroups per CU, split a power of two <= H/32
+    while (split < H / NSLICE && row_blocks * split < int64_t(2) * cus) split *= 2;
+    while ((H / NSLICE) % split) split /= 2;
+    hipLaunchKernelGGL((lstm_cell_mfma_kernel<KX, KH>), dim3(unsigned(row_blocks), unsigned(split)), dim3(256), 0, st, (const uint16_t*)x,
+                       (const uint16_t*)h_prev, c_prev, keep, (const uint16_t*)W, bias, (uint16_t*)h_out, c_out, h_out_f32, B, H, split);
     return int(hipGetLastError());
 }
 
