@@ -40,11 +40,13 @@ class PPOConfig:
     max_grad_norm: float = 0.5
     normalize_advantage: bool = True
     bootstrap_timeouts: bool = False
+    reward_scale: float = 1.0    # rewards are multiplied by this before GAE (1.0 = the reference's raw rewards; its -100 crash
+                                 # penalty makes value targets O(100), so the shared grad-norm clip starves the actor at large batch)
 
     @classmethod
     def from_dict(cls, d: dict, **over):
         keys = {"learning_rate", "n_steps", "n_epochs", "gamma", "gae_lambda", "clip_range", "clip_range_vf",
-                "ent_coef", "vf_coef", "max_grad_norm"}
+                "ent_coef", "vf_coef", "max_grad_norm", "n_minibatches", "bootstrap_timeouts", "reward_scale"}
         kw = {k: v for k, v in d.items() if k in keys}
         kw.update(over)
         return cls(**kw)
@@ -161,6 +163,8 @@ class RecurrentPPO:
             self.buf_logp[t].copy_(logp); self.buf_start[t].copy_(self.episode_start)
             obs, rew, term, trunc = env.step_device(actions)          # clip happens in-kernel (rate_env.py:225)
             self.buf_rew[t].copy_(rew)
+            if cfg.reward_scale != 1.0:
+                self.buf_rew[t].mul_(cfg.reward_scale)
             if cfg.bootstrap_timeouts:
                 # time-limit truncation is not failure: add gamma * V(s_T) (vec-env 'TimeLimit.truncated' handling).
                 # The post-step critic state belongs to the finished episode, so it can value the terminal observation.
@@ -235,8 +239,8 @@ class RecurrentPPO:
                     stats["clip_frac"] += ((ratio - 1).abs() > cfg.clip_range).float().mean()
                     stats["grad_norm"] += gn; stats["n"] += 1
         n = max(stats.pop("n"), 1)
-        self.last_stats = {k: float(v) / n for k, v in stats.items()}
-        self.last_stats["mean_reward_per_step"] = float(self.buf_rew.mean())
+        self.last_stats = {k: float(v.detach() if torch.is_tensor(v) else v) / n for k, v in stats.items()}
+        self.last_stats["mean_reward_per_step"] = float(self.buf_rew.mean()) / cfg.reward_scale
         return self.last_stats
 
     def learn(self, total_timesteps: int, log_interval: int = 1, callback=None):
@@ -253,7 +257,8 @@ class RecurrentPPO:
                 fps = self.cfg.n_steps * self.env.num_envs * world * it / max(time.time() - t0, 1e-9)
                 print(f"[ppo] iter {it} steps {self.num_timesteps * world} fps {fps:,.0f} "
                       f"rew/step {st['mean_reward_per_step']:.3f} pl {st['policy_loss']:.4f} vl {st['value_loss']:.3f} "
-                      f"kl {st['approx_kl']:.4f} clip {st['clip_frac']:.3f}", flush=True)
+                      f"kl {st['approx_kl']:.4f} clip {st['clip_frac']:.3f} gnorm {st['grad_norm']:.2f} "
+                      f"std {float(self.policy.log_std.exp().mean()):.3f}", flush=True)
         return self
 
     def save(self, path):

@@ -2,8 +2,8 @@
 """Train the learned rate controller: same CLI and config schema as the reference's learned_controllers/train_rate.py
 (:62-209) -- `--config`, `--no-lstm` -- with the curriculum loop of :150-180, on the device-resident env.
 
-    python -m hcrl_amd.train_rate --config <yaml>                       (1 GPU)
-    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m hcrl_amd.train_rate ...   (8 GPUs)
+    python train_rate.py --config <yaml>                                (1 GPU; repo-root wrapper)
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train_rate.py ...   (8 GPUs)
 """
 import argparse
 import os
@@ -27,6 +27,8 @@ def main(argv=None):
     ap.add_argument("--bc-pretrain", type=int, default=0, help="behaviour-cloning epochs on fused-PID demonstrations")
     ap.add_argument("--timesteps-scale", type=float, default=1.0)
     ap.add_argument("--precision", default="mixed")
+    ap.add_argument("--set", action="append", default=[], metavar="SECTION.KEY=VALUE",
+                    help="override a config entry, e.g. --set ppo.learning_rate=1e-3 --set training.n_envs=4096")
     ap.add_argument("--bf16", action="store_true", help="run the policy GEMMs in bf16 (fp32 accumulate)")
     args = ap.parse_args(argv)
 
@@ -38,6 +40,17 @@ def main(argv=None):
     rank = dist.get_rank() if world > 1 else 0
 
     config = load_config(args.config)
+    for item in args.set:                                   # SECTION.KEY=VALUE overrides (YAML-typed values)
+        import yaml as _yaml
+        key, val = item.split("=", 1)
+        sec, k = key.split(".", 1)
+        v = _yaml.safe_load(val)
+        if isinstance(v, str):                              # YAML 1.1 reads '1e-3' as a string
+            try:
+                v = float(v)
+            except ValueError:
+                pass
+        config.setdefault(sec, {})[k] = v
     seed = config.get("seed", 42)
     np.random.seed(seed)
     n_envs = config["training"]["n_envs"]
