@@ -250,8 +250,9 @@ _GUIDANCE = {"LOS": L.FD_GUIDANCE_LOS, "PP": L.FD_GUIDANCE_PP, "PURE_PURSUIT": L
 def cascade_consts(config: Optional[ControllerConfig] = None,
                    flight_config: Optional[FlightControlConfig] = None,
                    guidance_type: str = "LOS", acceptance_radius: Optional[float] = None,
-                   on_complete: str = "freeze") -> np.ndarray:
-    """[FD_NC] float64 glue constants of the cascade."""
+                   on_complete: str = "freeze", pid_throttle: float = 0.6, pid_dt: float = 0.0) -> np.ndarray:
+    """[FD_NC] float64 glue constants of the cascade.  pid_throttle / pid_dt: what the env kernels' fused rate-PID
+    driver holds / hands its PIDs (0.6 and the env dt for demonstrations, 0.5 and rate_loop_dt for eval_rate.py)."""
     c = config or ControllerConfig()
     hsa = flight_config.hsa if flight_config is not None else HSAConfig()
     g = flight_config.guidance if flight_config is not None else GuidanceConfig()
@@ -279,4 +280,6 @@ def cascade_consts(config: Optional[ControllerConfig] = None,
     C[L.FD_C_MIN_SPEED] = g.min_speed
     C[L.FD_C_ACCEPTANCE_RADIUS] = g.acceptance_radius if acceptance_radius is None else acceptance_radius
     C[L.FD_C_ON_COMPLETE] = {"freeze": 0, "restart": 1}[on_complete]
+    C[L.FD_C_PID_THROTTLE] = pid_throttle
+    C[L.FD_C_PID_DT] = pid_dt
     return C

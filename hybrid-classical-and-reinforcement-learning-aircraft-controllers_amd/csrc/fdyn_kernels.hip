@@ -471,7 +471,8 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
                 cfg[k] = load_pid_cfg(s_pid_cfg, k);
                 st[k] = PidState{ pid_state[(k * FD_NPS + 0) * n + i], pid_state[(k * FD_NPS + 1) * n + i], pid_state[(k * FD_NPS + 2) * n + i] };
             }
-            const Surfaces<S> sf = rate_agent<S>(cfg, st, s_consts, e.cmd[0], e.cmd[1], e.cmd[2], S(0.6), x, ec.dt);
+            const S pid_dt = s_consts[FD_C_PID_DT] > S(0) ? s_consts[FD_C_PID_DT] : ec.dt;
+            const Surfaces<S> sf = rate_agent<S>(cfg, st, s_consts, e.cmd[0], e.cmd[1], e.cmd[2], s_consts[FD_C_PID_THROTTLE], x, pid_dt);
             a_in[0] = float(sf.aileron); a_in[1] = float(sf.elevator); a_in[2] = float(sf.rudder); a_in[3] = float(sf.throttle);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {

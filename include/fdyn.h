@@ -157,6 +157,20 @@ int fdyn_policy_heads(const void* pi_hidden, const void* vf_hidden, const void* 
 int fdyn_gae(const float* rewards, const float* values, const float* episode_starts, const float* last_values,
              const float* last_dones, float gamma, float lam, int T, int64_t N, float* adv, float* ret, void* stream);
 
+
+/* ---- evaluation metrics (csrc/eval_kernels.hip) -----------------------------------------------------------------------
+ * MetricsCalculator.compute_metrics (learned_controllers/eval/metrics.py:95-362) for n recorded episodes at once.
+ * times [T] fp64 shared time base (times[t] = env time after step t+1, as eval_rate.py:104,219 records info["time"]);
+ * rates, commands [T][3][n]; actions [T][n][4] fp32; rewards [T][n]; lengths [n] int32 = steps of each episode (<= T);
+ * settle_steps = int(settling_duration / dt).  out [FD_NM][n] fp64 in RateControlMetrics field order (FD_M_*; success
+ * as 0/1).  An axis whose |command| stays < 0.01 keeps zeros (metrics.py:144-145); a zero-length episode gives zeros. */
+int fdyn_rate_metrics_f64(const double* times, const double* rates, const double* commands, const float* actions,
+                          const double* rewards, const int32_t* lengths, double settling_threshold, int settle_steps,
+                          int T, int64_t n, double* out, void* stream);
+int fdyn_rate_metrics_f32(const double* times, const float* rates, const float* commands, const float* actions,
+                          const float* rewards, const int32_t* lengths, double settling_threshold, int settle_steps,
+                          int T, int64_t n, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

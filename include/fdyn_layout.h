@@ -69,7 +69,11 @@ enum {
     FD_C_TURN_THRESHOLD_DIST, FD_C_TURN_THRESHOLD_ANGLE_RAD, FD_C_MAX_SPEED_REDUCTION, FD_C_MIN_SPEED,
     FD_C_ACCEPTANCE_RADIUS,
     FD_C_ON_COMPLETE,                                                 /* 0 freeze, 1 restart mission */
-    FD_NC = 24
+    /* fused rate-PID driver of the env kernels: throttle it holds (0.6 in pid_demonstrations.py:62 and
+     * residual_rate_env.py:113, 0.5 in eval_rate.py:196) and the dt it hands the PIDs (0 = the env dt, as
+     * pid_demonstrations.py:66; eval_rate.py:200 passes none => ControllerConfig.rate_loop_dt, types.py:342) */
+    FD_C_PID_THROTTLE, FD_C_PID_DT,
+    FD_NC = 28
 };
 enum { FD_GUIDANCE_LOS = 0, FD_GUIDANCE_PP = 1, FD_GUIDANCE_DEFAULT = 2 };
 enum { FD_WP_NORTH = 0, FD_WP_EAST, FD_WP_ALTITUDE, FD_WP_SPEED, FD_NWP = 4 };  /* waypoint row */
@@ -114,5 +118,15 @@ enum {
 enum { FD_EV_ENV = 0, FD_EV_LENGTH, FD_EV_TERMINATED, FD_EV_NI = 3 };           /* int32 part      */
 /* float part: [0] = episode return, [1..18] = terminal observation                                  */
 #define FD_EV_NF (1 + FD_OBS_DIM)
+
+/* ---- per-episode evaluation metrics, learned_controllers/eval/metrics.py:8-40 (field order of RateControlMetrics) */
+enum {
+    FD_M_SETTLE_ROLL = 0, FD_M_SETTLE_PITCH, FD_M_SETTLE_YAW,          /* s                           */
+    FD_M_OVERSHOOT_ROLL, FD_M_OVERSHOOT_PITCH, FD_M_OVERSHOOT_YAW,     /* %                           */
+    FD_M_SSERR_ROLL, FD_M_SSERR_PITCH, FD_M_SSERR_YAW,                 /* rad/s                       */
+    FD_M_RISE_ROLL, FD_M_RISE_PITCH, FD_M_RISE_YAW,                    /* s                           */
+    FD_M_SMOOTHNESS, FD_M_RMSE, FD_M_SUCCESS, FD_M_EPISODE_LENGTH, FD_M_TOTAL_REWARD,
+    FD_NM = 17
+};
 
 #endif /* FDYN_LAYOUT_H */

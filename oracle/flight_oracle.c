@@ -7,6 +7,7 @@
 #include "flight_oracle.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -536,7 +537,7 @@ void orc_residual_env_step(const double *P, const double *EC, const float *pid_c
 {   /* learned_controllers/envs/residual_rate_env.py:99-157 (float32 action arithmetic as NumPy does it) */
     const double cmd[3] = { e[FD_E_CMD_P], e[FD_E_CMD_Q], e[FD_E_CMD_R] };
     double surf[FD_NU];
-    orc_rate_agent(pid_cfg, pid_state, C, cmd, 0.6, x, EC[FD_EC_DT], surf);
+    orc_rate_agent(pid_cfg, pid_state, C, cmd, C[FD_C_PID_THROTTLE], x, C[FD_C_PID_DT] > 0.0 ? C[FD_C_PID_DT] : EC[FD_EC_DT], surf);
     const float pid_a[4] = { (float)surf[FD_U_AILERON], (float)surf[FD_U_ELEVATOR], (float)surf[FD_U_RUDDER], (float)surf[FD_U_THROTTLE] };
     float comb[4];
     for (int i = 0; i < 4; ++i) {
@@ -550,6 +551,99 @@ void orc_residual_env_step(const double *P, const double *EC, const float *pid_c
     const double bonus = 0.05 * (1.0 - (double)mag / 3.0);   /* numpy<2: float32 scalar / python float -> float64 */
     *reward += bonus;
     e[FD_E_EP_RETURN] += bonus;
+}
+
+/* ---------- evaluation metrics: learned_controllers/eval/metrics.py:95-362 ---------------------------------- */
+/* NumPy's pairwise summation of a strided fp64 vector (what np.sum / np.mean run for these reductions), restated so the
+ * oracle is bit-comparable with the reference's outputs: < 8 elements sequential; <= 128 eight running partial sums
+ * combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus a sequential tail; longer inputs split in halves (multiple of 8). */
+static double np_pairwise(const double *a, long n, long stride)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (long i = 0; i < n; ++i) res += a[i * stride];
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j * stride];
+        long i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[(i + j) * stride];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i * stride];
+        return res;
+    }
+    long n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise(a, n2, stride) + np_pairwise(a + n2 * stride, n - n2, stride);
+}
+
+void orc_rate_metrics(const double *times, const double *rates, const double *commands, const double *actions,
+                      const double *rewards, int len, double settling_threshold, int settle_steps, double out[FD_NM])
+{
+    for (int k = 0; k < FD_NM; ++k) out[k] = 0.0;
+    if (len <= 0) return;
+    double *tmp = (double *)malloc(sizeof(double) * (size_t)len * 3);
+    const double t_end = times[len - 1];
+    for (int ax = 0; ax < 3; ++ax) {                                              /* metrics.py:138-163 */
+        double max_cmd = 0.0;
+        for (int i = 0; i < len; ++i) max_cmd = fmax(max_cmd, fabs(commands[i * 3 + ax]));
+        if (max_cmd < 0.01) continue;                                             /* :144-145 */
+        /* _compute_settling_time :182-216 */
+        const double thr = pymax(settling_threshold * max_cmd, 0.05);
+        double settle = t_end;
+        for (int i = 0; i < len - settle_steps; ++i) {
+            int all = 1;
+            for (int j = i; j < i + settle_steps; ++j)
+                if (!(fabs(commands[j * 3 + ax] - rates[j * 3 + ax]) < thr)) { all = 0; break; }
+            if (all) { settle = times[i]; break; }
+        }
+        out[FD_M_SETTLE_ROLL + ax] = settle;
+        /* _compute_overshoot :218-257 */
+        const double sgn = signd(commands[(len / 2) * 3 + ax]);
+        double over = 0.0;
+        if (sgn != 0.0) {
+            double mx = 0.0; int any = 0;
+            for (int i = 0; i < len; ++i) {
+                const double err = rates[i * 3 + ax] - commands[i * 3 + ax];
+                if (sgn * err > 0.0) { any = 1; mx = fmax(mx, fabs(err)); }
+            }
+            if (any) over = (mx / max_cmd) * 100.0;
+        }
+        out[FD_M_OVERSHOOT_ROLL + ax] = over;
+        /* _compute_rise_time :259-294 */
+        const int n_ss = len / 5 > 1 ? len / 5 : 1;
+        const double cmd_ss = np_pairwise(commands + (size_t)(len - n_ss) * 3 + ax, n_ss, 3) / (double)n_ss;
+        double rise = 0.0;
+        if (!(fabs(cmd_ss) < 0.01)) {
+            const double th = 0.9 * cmd_ss;
+            rise = t_end;
+            for (int i = 0; i < len; ++i) {
+                const double r = rates[i * 3 + ax];
+                if (cmd_ss > 0.0 ? r >= th : r <= th) { rise = times[i]; break; }
+            }
+        }
+        out[FD_M_RISE_ROLL + ax] = rise;
+        /* _compute_steady_state_error :296-321 ; np.searchsorted(times, settle) (left) */
+        int idx = 0;
+        while (idx < len && times[idx] < settle) ++idx;
+        for (int i = 0; i < len; ++i) tmp[i] = fabs(commands[i * 3 + ax] - rates[i * 3 + ax]);
+        if (idx >= len - 1) out[FD_M_SSERR_ROLL + ax] = np_pairwise(tmp, len, 1) / (double)len;
+        else out[FD_M_SSERR_ROLL + ax] = np_pairwise(tmp + idx, len - idx, 1) / (double)(len - idx);
+    }
+    /* _compute_smoothness :323-340 (surfaces only); a one-step episode gives NumPy's mean of nothing = NaN */
+    for (int i = 0; i + 1 < len; ++i)
+        for (int k = 0; k < 3; ++k) tmp[i * 3 + k] = fabs(actions[(i + 1) * 4 + k] - actions[i * 4 + k]);
+    out[FD_M_SMOOTHNESS] = len > 1 ? np_pairwise(tmp, (long)(len - 1) * 3, 1) / (double)((len - 1) * 3) : NAN;
+    /* _compute_tracking_rmse :342-358 */
+    for (int i = 0; i < len * 3; ++i) { const double e = commands[i] - rates[i]; tmp[i] = e * e; }
+    out[FD_M_RMSE] = sqrt(np_pairwise(tmp, (long)len * 3, 1) / (double)(len * 3));
+    out[FD_M_SUCCESS] = (out[FD_M_SETTLE_ROLL] < t_end && out[FD_M_SETTLE_PITCH] < t_end &&
+                         out[FD_M_SETTLE_YAW] < t_end) ? 1.0 : 0.0;               /* :171-176 */
+    out[FD_M_EPISODE_LENGTH] = t_end;
+    out[FD_M_TOTAL_REWARD] = np_pairwise(rewards, len, 1);
+    free(tmp);
 }
 
 /* ---------- batch drivers (SoA) -------------------------------------------------------------------------- */

@@ -41,6 +41,7 @@ def _load():
         "orc_env_reset": (None, [_d, _d, _d, _i, _d, _f]),
         "orc_env_step": (None, [_d, _d, _d, _d, _i, _f, _d, _f, _d, _i, _i]),
         "orc_residual_env_step": (None, [_d, _d, _f, _f, _d, _d, _d, _i, _f, C.c_float, _d, _f, _d, _i, _i, _f]),
+        "orc_rate_metrics": (None, [_d, _d, _d, _d, _d, C.c_int, C.c_double, C.c_int, _d]),
         "orc_sixdof_step_batch": (None, [_d, _d, _d, C.c_int64, C.c_double, C.c_int, C.c_int]),
         "orc_env_step_batch": (None, [_d, _d, _d, _d, _i, _f, _f, _d, _i, _i, C.c_int64, C.c_int]),
         "orc_cascade_step_batch": (None, [_d, _f, _f, _d, _d, C.c_int, _i, _d, _d, C.c_int64, C.c_double,
@@ -106,3 +107,14 @@ def rk4_step(P, x, u, dt):
 
 def backend_step(P, x, u, dt, dt_physics=0.001):
     return lib.orc_backend_step(dp(P), dp(x), dp(u), dt, dt_physics)
+
+
+def rate_metrics(times, rates, commands, actions, rewards, settling_threshold=0.05, settle_steps=10):
+    """MetricsCalculator.compute_metrics (metrics.py:95-180) for one episode -> float64[FD_NM]."""
+    from hcrl_amd import layout as L
+    c = lambda a: np.ascontiguousarray(a, np.float64)
+    times, rates, commands, actions, rewards = c(times), c(rates), c(commands), c(actions), c(rewards)
+    out = np.zeros(L.FD_NM)
+    lib.orc_rate_metrics(dp(times), dp(rates), dp(commands), dp(actions), dp(rewards), len(times),
+                         float(settling_threshold), int(settle_steps), dp(out))
+    return out

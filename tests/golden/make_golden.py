@@ -656,9 +656,74 @@ def gen_env():
          tracking_reward=r1, components=comps, settle_reward=r2, settled=st)
 
 
+def gen_eval():
+    """Episode trajectories recorded the way eval_rate.py:129-235 (evaluate_pid_controller) does -- pre-step rates and
+    command, post-step time, float64 RateAgent actions, throttle 0.5, PID dt = ControllerConfig.rate_loop_dt -- and the
+    reference's MetricsCalculator.compute_metrics / aggregate over them (learned_controllers/eval/metrics.py:95-362)."""
+    print("eval metrics (reference MetricsCalculator)")
+    metrics_mod = _load_by_path("_ref_metrics", "learned_controllers/eval/metrics.py")
+    calc = metrics_mod.MetricsCalculator()
+    fields = list(metrics_mod.RateControlMetrics.__dataclass_fields__)
+    assert fields[:3] == ["settling_time_roll", "settling_time_pitch", "settling_time_yaw"] and len(fields) == 17
+    eps = []
+    for diff, ct, seed in (("easy", "step", 3), ("medium", "step", 11), ("hard", "step", 21), ("medium", "ramp", 9),
+                           ("medium", "sine", 13), ("hard", "random", 5), ("easy", "step", 42), ("medium", "step", 8)):
+        env = RefComposedRateEnv(difficulty=diff, command_type=ct, rng_seed=seed)
+        env.reset(seed=seed)
+        pid = RateAgent(ControllerConfig())
+        x0, cmd0 = state_vec(env.sim._physics), env.rate_command.copy()
+        times, rates, cmds, acts, rews = [], [], [], [], []
+        while True:
+            st = env.sim.get_state()
+            rc = env.rate_command.copy()
+            c = ControlCommand(mode=ControlMode.RATE, roll_rate=rc[0], pitch_rate=rc[1], yaw_rate=rc[2], throttle=0.5)
+            sf = pid.compute_action(c, st)
+            a = np.array([sf.aileron, sf.elevator, sf.rudder, sf.throttle])
+            _, r, term, trunc, _ = env.step(a)
+            times.append(env.t); rates.append([st.p, st.q, st.r]); cmds.append(rc); acts.append(a); rews.append(r)
+            if term or trunc:
+                break
+        eps.append(dict(times=np.array(times), rates=np.array(rates), commands=np.array(cmds), actions=np.array(acts),
+                        rewards=np.array(rews), x0=x0, cmd0=cmd0, terminated=term))
+    # synthetic edge cases: second-order responses with overshoot, negative / zero / tiny commands, episodes shorter
+    # than the settling window, a late step, a response that never settles
+    rs = np.random.RandomState(31)
+    for L_, cmdv, zeta, noise in ((500, [0.8, -0.5, 0.0], 0.3, 0.0), (500, [0.005, 0.2, -0.9], 0.7, 0.01),
+                                  (7, [0.4, 0.4, 0.4], 0.5, 0.0), (11, [0.3, -0.3, 0.02], 0.9, 0.0),
+                                  (260, [-1.2, 0.05, 0.6], 0.15, 0.05), (500, [0.0, 0.0, 0.0], 0.5, 0.0),
+                                  (2, [0.5, 0.0, 0.0], 0.5, 0.0), (137, [0.6, -0.6, 0.3], 0.05, 0.2)):
+        t = 0.02 * np.cumsum(np.ones(L_))
+        wn = np.array([6.0, 4.0, 9.0])
+        wd = wn * np.sqrt(1 - zeta ** 2)
+        resp = 1 - np.exp(-zeta * wn * t[:, None]) * (np.cos(wd * t[:, None]) + zeta / np.sqrt(1 - zeta ** 2) * np.sin(wd * t[:, None]))
+        cmd = np.tile(np.array(cmdv, dtype=float), (L_, 1))
+        if L_ == 260:
+            cmd[:40] = 0.0                                              # late step
+        rate = cmd * resp + noise * rs.normal(size=(L_, 3))
+        act = np.clip(np.cumsum(rs.normal(0, 0.03, (L_, 4)), 0), -1, 1)
+        eps.append(dict(times=np.cumsum(np.full(L_, 0.02)), rates=rate, commands=cmd, actions=act,
+                        rewards=rs.normal(0.5, 0.3, L_), x0=np.zeros(12), cmd0=np.zeros(3), terminated=False))
+    out, agg_in = {}, []
+    for j, e in enumerate(eps):
+        with np.errstate(all="ignore"):
+            m = calc.compute_metrics(e["times"], e["rates"], e["commands"], e["actions"], e["rewards"])
+        agg_in.append(m)
+        for k_, v in e.items():
+            out[f"ep{j}_{k_}"] = np.asarray(v)
+        out[f"ep{j}_metrics"] = np.array([float(getattr(m, f)) for f in fields])
+        print("   ep", j, "len", len(e["times"]), "settle", out[f"ep{j}_metrics"][:3], "success", m.success)
+    # aggregate_metrics (eval_rate.py:238-263) is in a module that imports SB3 at the top, so it cannot be imported;
+    # its arithmetic (np.mean per field, success rate) is applied to the reference's per-episode outputs here.
+    out["n_episodes"] = np.array(len(eps))
+    out["fields"] = np.array(fields)
+    out["settling_threshold"] = np.array(calc.settling_threshold)
+    out["settle_steps"] = np.array(int(calc.settling_duration / calc.dt))
+    save("eval_metrics.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["open", "stress", "pid", "agents", "cfg1", "cfg3", "samplers", "env"]
+    which = sys.argv[1:] or ["open", "stress", "pid", "agents", "cfg1", "cfg3", "samplers", "env", "eval"]
     for w in which:
         {"open": gen_open_loop, "stress": gen_stress, "pid": gen_pid, "agents": gen_agents, "cfg1": gen_cfg1,
-         "cfg3": gen_cfg3, "samplers": gen_samplers, "env": gen_env}[w]()
+         "cfg3": gen_cfg3, "samplers": gen_samplers, "env": gen_env, "eval": gen_eval}[w]()
     print("done")

@@ -342,3 +342,15 @@ def test_residual_env_episode(oracle):
         assert abs(r[0] - g["rewards"][k]) < 1e-6, k
         assert (te[0], tr[0]) == tuple(int(v) for v in g["flags"][k])
         assert rel_err(obs, g["obs"][k + 1]).max() < 1e-6, k
+
+
+def test_eval_metrics_match_reference_calculator(oracle):
+    """MetricsCalculator.compute_metrics (learned_controllers/eval/metrics.py:95-362): 8 PID episodes recorded the way
+    eval_rate.py does + 8 synthetic edge cases.  Times, flags and the pairwise-summed means are bit-exact."""
+    g = load_golden("eval_metrics.npz")
+    for j in range(int(g["n_episodes"])):
+        pre = f"ep{j}_"
+        got = oracle.rate_metrics(g[pre + "times"], g[pre + "rates"], g[pre + "commands"], g[pre + "actions"],
+                                  g[pre + "rewards"], float(g["settling_threshold"]), int(g["settle_steps"]))
+        want = g[pre + "metrics"]
+        assert np.array_equal(got, want, equal_nan=True), (j, got - want)
