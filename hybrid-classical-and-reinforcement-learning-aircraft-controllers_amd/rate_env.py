@@ -26,7 +26,7 @@ class GpuRateVecEnv:
                  command_type: str = "step", seed: Optional[int] = None, precision: str = "mixed",
                  sampling: str = "device", pool_depth: int = 8, types: Sequence = ("rc_plane",),
                  type_index: Optional[np.ndarray] = None, event_capacity: Optional[int] = None,
-                 numpy_io: bool = False, device=None, residual_scale: float = 0.0):
+                 numpy_io: bool = False, device=None, residual_scale: float = 0.0, sensor_noise: Optional[dict] = None):
         self.lib = _lib.load()
         self.device = device or _lib.require_gpu()
         self.num_envs = self.n = int(num_envs)
@@ -73,6 +73,12 @@ class GpuRateVecEnv:
                 self._streams = [EpisodeStreams(difficulty, command_type, s) for s in seeds]
         elif sampling != "device":
             raise ValueError("sampling must be 'parity' or 'device'")
+        # optional sensor layer between the physics and the policy (interfaces/sensor.py:137-243 noise model on the obs)
+        self.sensor = None
+        if sensor_noise is not None:
+            from .sensors import ObservationNoise
+            self.sensor = ObservationNoise(sensor_noise, n, dev)
+            self._done_mask = torch.zeros(n, dtype=torch.uint8, device=dev)
         self._reset_fn = getattr(self.lib, f"fdyn_rate_env_reset_{precision}")
         self._step_fn = getattr(self.lib, f"fdyn_rate_env_step_{precision}")
         self._pending = None
@@ -84,6 +90,15 @@ class GpuRateVecEnv:
                             _lib.ptr(m), _lib.ptr(self.env_consts), _lib.ptr(self.pool), self.pool_depth,
                             self.seed_value, _lib.ptr(self.obs), self.n, _lib.current_stream())
         _lib.check(rc, "RateControlEnv.reset")
+        if self.sensor is not None:
+            if m is None:
+                self.sensor.reset()
+                self.sensor.apply(self.obs)
+            else:       # a masked reset restarts the bias walk of the reset envs only; obs rows of the others are unchanged
+                keep, keep_bias, mb = self.obs.clone(), self.sensor.gyro_bias.clone(), m.bool()
+                self.sensor.apply(self.obs, m)
+                self.obs.copy_(torch.where(mb[:, None], self.obs, keep))
+                self.sensor.gyro_bias.copy_(torch.where(mb[None, :], self.sensor.gyro_bias, keep_bias))
         return self._out(self.obs)
 
     def step_device(self, actions: Optional[torch.Tensor], auto_reset: bool = True, rw_delta=None):
@@ -102,6 +117,12 @@ class GpuRateVecEnv:
                            cur.data_ptr(), nxt.data_ptr(), _lib.ptr(self.ev_int), _lib.ptr(self.ev_flt), self.ev_cap,
                            self.n, _lib.current_stream())
         _lib.check(rc, "RateControlEnv.step")
+        if self.sensor is not None:
+            mask = None
+            if auto_reset:                                     # obs rows of finished envs are first observations
+                torch.bitwise_or(self.terminated, self.truncated, out=self._done_mask)
+                mask = self._done_mask
+            self.sensor.apply(self.obs, mask)
         return self.obs, self.rewards, self.terminated, self.truncated
 
     def step(self, actions, auto_reset: bool = True):

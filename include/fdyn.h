@@ -171,6 +171,24 @@ int fdyn_rate_metrics_f32(const double* times, const float* rates, const float* 
                           const float* rewards, const int32_t* lengths, double settling_threshold, int settle_steps,
                           int T, int64_t n, double* out, void* stream);
 
+
+/* ---- sensor layer (csrc/sensor_kernels.hip) ---------------------------------------------------------------------------
+ * NoisySensorInterface.update (interfaces/sensor.py:199-243) for n aircraft: meas [FD_NMS][n] = the 12 state words +
+ * airspeed + altitude with Gaussian noise, body rates additionally offset by the gyro bias; bias [FD_NSB][n]
+ * (gyro 3 | accel 3) random-walks in place (sensor.reset() = zero it).  x [FD_NX][n]; derived [FD_ND][n] (the backend's
+ * airspeed / altitude rows) or NULL = computed from x; noise_cfg [FD_NSN] fp64 (FD_SN_*; FD_SN_ENABLED = 0 copies the
+ * truth through).  z [FD_NSZ][n] = this update's standard normals in the reference's draw order (parity mode), or NULL =
+ * in-kernel Philox keyed by (seed, aircraft, *step); step = uint32 in device memory (NULL = 0).                          */
+int fdyn_sensor_update_f64(const double* x, const double* derived, double* bias, const double* noise_cfg, const double* z,
+                           uint64_t seed, const uint32_t* step, double* meas, int64_t n, void* stream);
+int fdyn_sensor_update_f32(const float* x, const float* derived, float* bias, const double* noise_cfg, const float* z,
+                           uint64_t seed, const uint32_t* step, float* meas, int64_t n, void* stream);
+/* The same model applied in place to rate-control observations obs [n][18] (rate_env.py:374-408): rates += noise + gyro
+ * bias, rate errors recomputed from the measured rates, airspeed / altitude / attitude += noise; gyro_bias [3][n] fp32
+ * walks in place and restarts from zero where reset_mask [n] (NULL = never) is set (first observation of an episode).  */
+int fdyn_sensor_observe(float* obs, float* gyro_bias, const uint8_t* reset_mask, const double* noise_cfg, const float* z,
+                        uint64_t seed, const uint32_t* step, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

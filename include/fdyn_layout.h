@@ -129,4 +129,20 @@ enum {
     FD_NM = 17
 };
 
+/* ---- sensor layer, interfaces/sensor.py:137-243 (NoisySensorInterface) ------------------------------------------- */
+/* noise configuration (fp64): standard deviations in the order the reference draws (:208-235), then the two bias
+ * random-walk steps it hard-codes (:233-234) and the enabled flag (:203-205)                                        */
+enum {
+    FD_SN_GPS_POS = 0, FD_SN_GPS_VEL, FD_SN_ATTITUDE, FD_SN_GYRO, FD_SN_AIRSPEED, FD_SN_ALTITUDE,
+    FD_SN_GYRO_BIAS_WALK, FD_SN_ACCEL_BIAS_WALK, FD_SN_ENABLED,
+    FD_NSN = 12
+};
+/* one update consumes 20 standard normals, in the reference's call order                                           */
+enum {
+    FD_SZ_POS = 0, FD_SZ_VEL = 3, FD_SZ_ATT = 6, FD_SZ_GYRO = 9, FD_SZ_AIRSPEED = 12, FD_SZ_ALTITUDE = 13,
+    FD_SZ_GYRO_BIAS = 14, FD_SZ_ACCEL_BIAS = 17, FD_NSZ = 20
+};
+/* measurement block: the 12 state words (FD_X_* order) + airspeed + altitude ; bias block: gyro(3) + accel(3)       */
+enum { FD_MS_AIRSPEED = 12, FD_MS_ALTITUDE = 13, FD_NMS = 14, FD_NSB = 6 };
+
 #endif /* FDYN_LAYOUT_H */

@@ -646,6 +646,30 @@ void orc_rate_metrics(const double *times, const double *rates, const double *co
     free(tmp);
 }
 
+/* ---------- sensor layer: interfaces/sensor.py:199-243 (NoisySensorInterface.update) ------------------------------ */
+void orc_sensor_update(const double x[FD_NX], double airspeed, double altitude, double bias[FD_NSB],
+                       const double cfg[FD_NSN], const double z[FD_NSZ], double meas[FD_NMS])
+{   /* rng.normal(0, s, k) is 0 + s * standard_normal: z holds the standard normals in the reference's call order.
+     * airspeed / altitude: the true state's derived fields (AircraftState.airspeed, .altitude) */
+    if (cfg[FD_SN_ENABLED] == 0.0) {                                              /* :203-205 */
+        for (int k = 0; k < FD_NX; ++k) meas[k] = x[k];
+        meas[FD_MS_AIRSPEED] = airspeed; meas[FD_MS_ALTITUDE] = altitude;
+        return;
+    }
+    for (int k = 0; k < 3; ++k) {
+        meas[FD_X_N + k] = x[FD_X_N + k] + (0.0 + cfg[FD_SN_GPS_POS] * z[FD_SZ_POS + k]);            /* :208-210 */
+        meas[FD_X_U + k] = x[FD_X_U + k] + (0.0 + cfg[FD_SN_GPS_VEL] * z[FD_SZ_VEL + k]);            /* :211-213 */
+        meas[FD_X_ROLL + k] = x[FD_X_ROLL + k] + (0.0 + cfg[FD_SN_ATTITUDE] * z[FD_SZ_ATT + k]);     /* :214-216 */
+        meas[FD_X_P + k] = (x[FD_X_P + k] + (0.0 + cfg[FD_SN_GYRO] * z[FD_SZ_GYRO + k])) + bias[k];  /* :217-221 */
+    }
+    meas[FD_MS_AIRSPEED] = airspeed + (0.0 + cfg[FD_SN_AIRSPEED] * z[FD_SZ_AIRSPEED]);               /* :222-224 */
+    meas[FD_MS_ALTITUDE] = altitude + (0.0 + cfg[FD_SN_ALTITUDE] * z[FD_SZ_ALTITUDE]);               /* :225-227 */
+    for (int k = 0; k < 3; ++k) {                                                                     /* :230-231 */
+        bias[k] += 0.0 + cfg[FD_SN_GYRO_BIAS_WALK] * z[FD_SZ_GYRO_BIAS + k];
+        bias[3 + k] += 0.0 + cfg[FD_SN_ACCEL_BIAS_WALK] * z[FD_SZ_ACCEL_BIAS + k];
+    }
+}
+
 /* ---------- batch drivers (SoA) -------------------------------------------------------------------------- */
 int orc_max_threads(void)
 {

@@ -42,6 +42,7 @@ def _load():
         "orc_env_step": (None, [_d, _d, _d, _d, _i, _f, _d, _f, _d, _i, _i]),
         "orc_residual_env_step": (None, [_d, _d, _f, _f, _d, _d, _d, _i, _f, C.c_float, _d, _f, _d, _i, _i, _f]),
         "orc_rate_metrics": (None, [_d, _d, _d, _d, _d, C.c_int, C.c_double, C.c_int, _d]),
+        "orc_sensor_update": (None, [_d, C.c_double, C.c_double, _d, _d, _d, _d]),
         "orc_sixdof_step_batch": (None, [_d, _d, _d, C.c_int64, C.c_double, C.c_int, C.c_int]),
         "orc_env_step_batch": (None, [_d, _d, _d, _d, _i, _f, _f, _d, _i, _i, C.c_int64, C.c_int]),
         "orc_cascade_step_batch": (None, [_d, _f, _f, _d, _d, C.c_int, _i, _d, _d, C.c_int64, C.c_double,
@@ -118,3 +119,14 @@ def rate_metrics(times, rates, commands, actions, rewards, settling_threshold=0.
     lib.orc_rate_metrics(dp(times), dp(rates), dp(commands), dp(actions), dp(rewards), len(times),
                          float(settling_threshold), int(settle_steps), dp(out))
     return out
+
+
+def sensor_update(x, airspeed, altitude, bias, cfg, z):
+    """NoisySensorInterface.update (sensor.py:199-243): returns meas[FD_NMS]; bias (float64[6]) walks in place."""
+    from hcrl_amd import layout as L
+    x, z = np.ascontiguousarray(x, np.float64), np.ascontiguousarray(z, np.float64)
+    c = np.zeros(L.FD_NSN)
+    c[:len(cfg)] = cfg
+    meas = np.zeros(L.FD_NMS)
+    lib.orc_sensor_update(dp(x), float(airspeed), float(altitude), dp(bias), dp(c), dp(z), dp(meas))
+    return meas

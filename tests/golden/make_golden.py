@@ -721,9 +721,47 @@ def gen_eval():
     save("eval_metrics.npz", **out)
 
 
+def gen_sensor():
+    """NoisySensorInterface (interfaces/sensor.py:137-243) over an open-loop flight: measured states and bias walks, plus
+    the standard normals its default_rng(seed) stream yields in the same call order (rng.normal(0, s, k) is
+    0 + s * standard_normal(k) on the same bit stream), so a checker can replay the update without NumPy's generator."""
+    print("sensor layer (reference NoisySensorInterface)")
+    sensor_mod = _load_by_path("_ref_sensor", "interfaces/sensor.py")
+    out = {}
+    for tag, cfg in (("default", {"seed": 7}),
+                     ("custom", {"seed": 11, "imu_gyro_stddev": 0.03, "gps_position_stddev": 2.5, "gps_velocity_stddev": 0.3,
+                                 "airspeed_stddev": 0.8, "altitude_stddev": 1.5, "attitude_stddev": 0.02}),
+                     ("disabled", {"seed": 3, "enabled": False})):
+        sim = Simplified6DOF()
+        sim.reset()
+        sim.set_controls(ControlSurfaces(elevator=0.05, aileron=0.1, rudder=-0.05, throttle=0.7))
+        sens = sensor_mod.NoisySensorInterface(dict(cfg))
+        replay = np.random.default_rng(cfg["seed"])
+        xs, zs, meas, bias, va = [], [], [], [], []
+        for k in range(200):
+            for _ in range(5):
+                sim.step(0.002)
+            st = sim.get_state()
+            xs.append(state_vec(sim))
+            va.append([st.airspeed, st.altitude])
+            sens.update(st)
+            m = sens.get_state()
+            meas.append(np.concatenate([m.position, m.velocity, m.attitude, m.angular_rate, [m.airspeed, m.altitude]]))
+            bias.append(np.concatenate([sens._gyro_bias, sens._accel_bias]))
+            zs.append(replay.standard_normal(20) if cfg.get("enabled", True) else np.zeros(20))
+        p_ = sens.get_noise_parameters()
+        out[f"{tag}_x"], out[f"{tag}_z"], out[f"{tag}_meas"], out[f"{tag}_bias"] = map(np.array, (xs, zs, meas, bias))
+        out[f"{tag}_airspeed_altitude"] = np.array(va)
+        out[f"{tag}_cfg"] = np.array([p_["gps_position_stddev"], p_["gps_velocity_stddev"], p_["attitude_stddev"],
+                                      p_["imu_gyro_stddev"], p_["airspeed_stddev"], p_["altitude_stddev"], 0.0001, 0.001,
+                                      float(p_["enabled"])])
+        print("  ", tag, "gyro bias after 200 updates", sens._gyro_bias)
+    save("sensor_noisy.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["open", "stress", "pid", "agents", "cfg1", "cfg3", "samplers", "env", "eval"]
+    which = sys.argv[1:] or ["open", "stress", "pid", "agents", "cfg1", "cfg3", "samplers", "env", "eval", "sensor"]
     for w in which:
         {"open": gen_open_loop, "stress": gen_stress, "pid": gen_pid, "agents": gen_agents, "cfg1": gen_cfg1,
-         "cfg3": gen_cfg3, "samplers": gen_samplers, "env": gen_env, "eval": gen_eval}[w]()
+         "cfg3": gen_cfg3, "samplers": gen_samplers, "env": gen_env, "eval": gen_eval, "sensor": gen_sensor}[w]()
     print("done")

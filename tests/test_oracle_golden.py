@@ -354,3 +354,16 @@ def test_eval_metrics_match_reference_calculator(oracle):
                                   g[pre + "rewards"], float(g["settling_threshold"]), int(g["settle_steps"]))
         want = g[pre + "metrics"]
         assert np.array_equal(got, want, equal_nan=True), (j, got - want)
+
+
+@pytest.mark.parametrize("tag", ["default", "custom", "disabled"])
+def test_sensor_update_matches_reference_noisy_sensor(oracle, tag):
+    """NoisySensorInterface.update (interfaces/sensor.py:199-243) over 200 updates: measured state and both bias random
+    walks, replayed from the standard normals of the reference's own generator stream.  Bit-exact."""
+    g = load_golden("sensor_noisy.npz")
+    bias = np.zeros(L.FD_NSB)
+    for k in range(len(g[f"{tag}_x"])):
+        va = g[f"{tag}_airspeed_altitude"][k]
+        meas = oracle.sensor_update(g[f"{tag}_x"][k], va[0], va[1], bias, g[f"{tag}_cfg"], g[f"{tag}_z"][k])
+        assert np.array_equal(meas, g[f"{tag}_meas"][k]), (k, meas - g[f"{tag}_meas"][k])
+        assert np.array_equal(bias, g[f"{tag}_bias"][k]), k
