@@ -1,0 +1,118 @@
+"""LearnedRateAgent (controllers/learned_rate_agent.py:26-284) over the device policy: the agent fed (command, state)
+must act exactly as the policy fed the env's own observation -- the property that lets a policy trained in
+GpuRateVecEnv sit in the cascade where the reference's SB3 agent sits.  SB3's .zip format is absent => parity unpinned
+for checkpoint files; the observation assembly (:158-178) and action clipping are what is checked.
+"""
+import numpy as np
+import pytest
+import torch
+
+from hcrl_amd import layout as L, config as cfgmod
+from hcrl_amd.flight_types import ControlCommand, ControlMode, ControllerConfig
+from hcrl_amd.gym_env import RateControlEnv
+from hcrl_amd.learned_rate_agent import BatchedLearnedRateAgent, LearnedRateAgent
+from hcrl_amd.policy import RateLSTMPolicy
+from hcrl_amd.rate_env import GpuRateVecEnv
+
+pytestmark = pytest.mark.gpu
+
+
+def _policy(seed=0):
+    torch.manual_seed(seed)
+    pol = RateLSTMPolicy(compute_dtype=torch.bfloat16).cuda()
+    with torch.no_grad():
+        pol.action_net.weight.mul_(30.0)                      # make the random policy move the surfaces (and hit the clip)
+    pol.prepare_inference()
+    return pol
+
+
+def test_agent_in_the_loop_equals_policy_on_env_observations(tmp_path):
+    pol = _policy()
+    path = tmp_path / "model.pt"
+    torch.save({"policy": pol.state_dict()}, path)
+    with pytest.raises(FileNotFoundError):
+        LearnedRateAgent(str(tmp_path / "missing.pt"), ControllerConfig())
+    agent = LearnedRateAgent(str(path), ControllerConfig(), fallback_to_pid=False)
+    assert agent.get_control_level() == ControlMode.RATE and agent.is_recurrent and "RecurrentPPO" in repr(agent)
+    env = RateControlEnv("medium", 4.0, 0.02, "step", rng_seed=5)
+    obs, info = env.reset(seed=5)
+    ref_pol = _policy()                                       # same weights, its own recurrent state, fed env observations
+    st = ref_pol.initial_state(1, "cuda")
+    start = torch.ones(1, device="cuda")
+    lo, hi = torch.tensor([-1.0, -1.0, -1.0, 0.0], device="cuda"), torch.ones(4, device="cuda")
+    clipped = 0
+    for k in range(120):
+        cmd = env.rate_command
+        command = ControlCommand(mode=ControlMode.RATE, roll_rate=cmd[0], pitch_rate=cmd[1], yaw_rate=cmd[2], throttle=0.5)
+        surf = agent.compute_action(command, env.sim.get_state())
+        a_ref, _, _, st = ref_pol.step(torch.as_tensor(obs[None], device="cuda"), st, start, deterministic=True)
+        start = torch.zeros(1, device="cuda")
+        a_ref = torch.minimum(torch.maximum(a_ref.float(), lo), hi)[0].cpu().numpy()
+        assert np.array_equal(agent.obs, obs), (k, agent.obs - obs)
+        got = np.array([surf.aileron, surf.elevator, surf.rudder, surf.throttle])
+        assert np.allclose(got, a_ref, atol=1e-6), (k, got, a_ref)
+        clipped += int(np.any(np.abs(a_ref[:3]) == 1.0))
+        obs, _, term, trunc, info = env.step(got.astype(np.float32))
+        if term or trunc:
+            break
+    assert k > 20
+    agent.reset()
+    assert np.array_equal(agent.prev_action, [0.0, 0.0, 0.0, 0.5]) and not agent.using_fallback
+
+
+def test_pid_fallback_is_the_rate_agent(oracle):
+    class Broken(torch.nn.Module):
+        use_lstm = True
+
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(1, device="cuda"))
+
+        def initial_state(self, n, dev):
+            return None
+
+        def step(self, *a, **k):
+            raise RuntimeError("inference failed")
+
+    cfg = ControllerConfig()
+    agent = LearnedRateAgent(None, cfg, fallback_to_pid=True, policy=Broken())
+    strict = LearnedRateAgent(None, cfg, fallback_to_pid=False, policy=Broken())
+    from hcrl_amd.flight_types import AircraftState
+    rs = np.random.RandomState(0)
+    pc, Cc = cfgmod.pid_table(cfg), cfgmod.cascade_consts(cfg)
+    ps = np.zeros((L.FD_NPID, L.FD_NPS), np.float32)
+    for k in range(40):
+        x = np.concatenate([[0, 0, -100], [20, 0, 0], rs.uniform(-0.2, 0.2, 3), rs.uniform(-1, 1, 3)])
+        state = AircraftState.from_vector(x, derived=(20.0, 100.0, 20.0, 0.0))
+        cmd = rs.uniform(-4, 4, 3)                           # beyond the 180 deg/s limit sometimes: clipped (:152-155)
+        command = ControlCommand(mode=ControlMode.RATE, roll_rate=cmd[0], pitch_rate=cmd[1], yaw_rate=cmd[2], throttle=0.55)
+        s = agent.compute_action(command, state, dt=0.01)
+        assert agent.using_fallback
+        surf = np.zeros(4)
+        oracle.lib.orc_rate_agent(oracle.fp(pc), oracle.fp(ps), oracle.dp(Cc), oracle.dp(cmd), 0.55, oracle.dp(x), 0.01,
+                                  oracle.dp(surf))
+        got = [s.elevator, s.aileron, s.rudder, s.throttle]
+        assert np.array_equal(np.array(got), surf), (k, got, surf)
+    with pytest.raises(RuntimeError):
+        strict.compute_action(command, state)
+
+
+def test_batched_agent_matches_vec_env_rollout():
+    """The fleet form: actions from (rate command rows, state block) equal the policy's actions on the vec-env's own
+    observations, including the clipped-action feedback through prev_action."""
+    pol, ref_pol = _policy(1), _policy(1)
+    n = 1024
+    env = GpuRateVecEnv(n, "hard", 10.0, 0.02, "step", seed=2, precision="mixed", sampling="device")
+    obs = env.reset()
+    agent = BatchedLearnedRateAgent(pol, n)
+    st, start = ref_pol.initial_state(n, "cuda"), torch.ones(n, device="cuda")
+    lo, hi = torch.tensor([-1.0, -1.0, -1.0, 0.0], device="cuda"), torch.ones(4, device="cuda")
+    for k in range(25):
+        a = agent.compute_actions(env.rate_command, env.x)
+        a_ref, _, _, st = ref_pol.step(obs, st, start, deterministic=True)
+        start = torch.zeros(n, device="cuda")
+        a_ref = torch.minimum(torch.maximum(a_ref.float(), lo), hi)
+        assert torch.allclose(agent.obs, obs, atol=2e-6, rtol=1e-6), (k, float((agent.obs - obs).abs().max()))
+        assert torch.allclose(a, a_ref, atol=2e-2), (k, float((a - a_ref).abs().max()))     # bf16 policy: obs differ by ulps
+        obs, _, _, _ = env.step_device(a_ref, auto_reset=False)
+        agent.prev_action = a_ref.clone()
