@@ -32,7 +32,7 @@ class BatchedLearnedRateAgent:
         self.policy, self.n = policy, int(n)
         self.device = device or next(policy.parameters()).device
         c = config or ControllerConfig()
-        self.max_rates = torch.tensor(np.radians([c.max_roll_rate, c.max_pitch_rate, c.max_yaw_rate]), dtype=torch.float32,
+        self.max_rates = torch.tensor(np.radians([c.max_roll_rate, c.max_pitch_rate, c.max_yaw_rate]), dtype=torch.float64,
                                       device=self.device)
         self.obs = torch.zeros((self.n, L.FD_OBS_DIM), dtype=torch.float32, device=self.device)
         self.reset()
@@ -51,7 +51,8 @@ class BatchedLearnedRateAgent:
     def compute_actions(self, rate_cmd: torch.Tensor, x: torch.Tensor, airspeed: Optional[torch.Tensor] = None,
                         altitude: Optional[torch.Tensor] = None) -> torch.Tensor:
         o = self.obs
-        cmd = torch.minimum(torch.maximum(rate_cmd.to(torch.float32), -self.max_rates), self.max_rates)   # :152-155
+        mr = self.max_rates.to(x.dtype)                      # clip and difference in the state's precision, then narrow
+        cmd = torch.minimum(torch.maximum(rate_cmd.to(x.dtype), -mr), mr)                                 # :152-155
         rates = x[L.FD_X_P:L.FD_X_R + 1].T
         if airspeed is None:
             airspeed = x[L.FD_X_U:L.FD_X_W + 1].to(torch.float64).square().sum(0).sqrt()
@@ -59,7 +60,7 @@ class BatchedLearnedRateAgent:
             altitude = -x[L.FD_X_D]
         o[:, 0:3] = rates
         o[:, 3:6] = cmd
-        o[:, 6:9] = (cmd.to(x.dtype) - rates)
+        o[:, 6:9] = cmd - rates
         o[:, 9], o[:, 10] = airspeed, altitude
         o[:, 11:14] = x[L.FD_X_ROLL:L.FD_X_YAW + 1].T
         o[:, 14:18] = self.prev_action

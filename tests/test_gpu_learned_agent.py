@@ -26,6 +26,7 @@ def _policy(seed=0):
     return pol
 
 
+@torch.no_grad()
 def test_agent_in_the_loop_equals_policy_on_env_observations(tmp_path):
     pol = _policy()
     path = tmp_path / "model.pt"
@@ -97,6 +98,7 @@ def test_pid_fallback_is_the_rate_agent(oracle):
         strict.compute_action(command, state)
 
 
+@torch.no_grad()
 def test_batched_agent_matches_vec_env_rollout():
     """The fleet form: actions from (rate command rows, state block) equal the policy's actions on the vec-env's own
     observations, including the clipped-action feedback through prev_action."""
