@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fused import lstm_cell
+from .fused import DeferredWgrad, deferred_linear, linear, lstm_cell
 
 OBS_DIM, ACT_DIM = 18, 4
 
@@ -56,7 +56,14 @@ def _lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh):
 
 
 def _lstm_zero_state_layer(x, w_ih, b_ih, b_hh):
-    return lstm_cell(F.linear(x, w_ih, b_ih + b_hh), None)[0]
+    return lstm_cell(linear(x, w_ih, b_ih + b_hh), None)[0]
+
+
+def _run_seq(seq, x):
+    """nn.Sequential of Linear / ReLU, with the Linears routed through fused.linear (split-K weight gradients)."""
+    for m in seq:
+        x = linear(x, m.weight, m.bias) if isinstance(m, nn.Linear) else m(x)
+    return x
 
 
 class LSTMFeaturesExtractor(nn.Module):
@@ -68,11 +75,11 @@ class LSTMFeaturesExtractor(nn.Module):
         self.output_proj = nn.Sequential(nn.Linear(lstm_hidden_size, features_dim), nn.ReLU())
 
     def forward(self, obs):
-        x = self.embedding(obs)
+        x = _run_seq(self.embedding, obs)
         for layer in range(self.lstm.num_layers):
             x = _lstm_zero_state_layer(x, getattr(self.lstm, f"weight_ih_l{layer}"), getattr(self.lstm, f"bias_ih_l{layer}"),
                                        getattr(self.lstm, f"bias_hh_l{layer}")).to(x.dtype)
-        return self.output_proj(x)
+        return _run_seq(self.output_proj, x)
 
 
 def _mlp(sizes):
@@ -90,6 +97,7 @@ class RateLSTMPolicy(nn.Module):
                  mlp_net_arch=(256, 128, 64), compute_dtype: Optional[torch.dtype] = None):
         super().__init__()
         self.use_lstm, self.hidden, self.compute_dtype = use_lstm, policy_lstm_hidden, compute_dtype
+        self.deferred_wgrad = True       # BPTT: one split-K weight-gradient GEMM per recurrent cell per backward pass
         if use_lstm:
             self.features_extractor = LSTMFeaturesExtractor(OBS_DIM, features_dim, lstm_hidden_size, n_lstm_layers)
             self.lstm_actor = nn.LSTM(features_dim, policy_lstm_hidden, 1)
@@ -267,9 +275,11 @@ class RateLSTMPolicy(nn.Module):
         values, logps = [], []
         with torch.autocast(obs.device.type, dtype=self.compute_dtype, enabled=self.compute_dtype is not None):
             if not self.use_lstm:
-                lat_pi, lat_vf, _ = self._core(obs.reshape(-1, OBS_DIM), states)
-                mean = self.action_net(lat_pi).float().view(T, -1, ACT_DIM)
-                return self.value_net(lat_vf).float().view(T, -1), self._log_prob(actions, mean), self.entropy()
+                flat = obs.reshape(-1, OBS_DIM)
+                lat_pi, lat_vf = _run_seq(self.pi_net, flat), _run_seq(self.vf_net, flat)
+                mean = linear(lat_pi, self.action_net.weight, self.action_net.bias).float().view(T, -1, ACT_DIM)
+                values = linear(lat_vf, self.value_net.weight, self.value_net.bias).float().view(T, -1)
+                return values, self._log_prob(actions, mean), self.entropy()
             # the zero-state feature extractor has no time dependence: run it for all T*B rows in one set of GEMMs
             feats = self.features_extractor(obs.reshape(-1, OBS_DIM)).view(T, -1, self.features_extractor.features_dim)
             la, lc = self.lstm_actor, self.lstm_critic
@@ -277,17 +287,31 @@ class RateLSTMPolicy(nn.Module):
             wc, bc = torch.cat([lc.weight_ih_l0, lc.weight_hh_l0], 1), lc.bias_ih_l0 + lc.bias_hh_l0
             pi_hs, vf_hs = [], []
             pi_h, pi_c, vf_h, vf_c = states
+            # BPTT with deferred weight gradients (fused.DeferredWgrad): each step's backward only produces dX; dW / db of
+            # the two recurrent cells come from one split-K GEMM over all T*B rows when the backward pass ends
+            defer = self.deferred_wgrad and feats.is_cuda and torch.is_grad_enabled()
+            if defer:
+                Bn, kx, dt = feats.shape[1], feats.shape[2], feats.dtype
+                wa, ba, wc, bc = wa.detach().to(dt), ba.detach().to(dt), wc.detach().to(dt), bc.detach().to(dt)
+                mk = lambda l, w: DeferredWgrad(T, Bn, w.shape[1], w.shape[0], dt, feats.device,   # noqa: E731
+                                                [(l.weight_ih_l0, slice(0, kx)), (l.weight_hh_l0, slice(kx, w.shape[1]))],
+                                                [l.bias_ih_l0, l.bias_hh_l0])
+                bk_a, bk_c = mk(la, wa), mk(lc, wc)
             for t in range(T):
                 keep = (1.0 - episode_starts[t].float()).unsqueeze(-1)
                 kh = keep.to(pi_h.dtype)
                 pi_h, pi_c, vf_h, vf_c = pi_h * kh, pi_c * keep, vf_h * kh, vf_c * keep
                 x = feats[t]
-                pi_h, pi_c = lstm_cell(F.linear(torch.cat([x, pi_h.to(x.dtype)], -1), wa, ba), pi_c)
-                vf_h, vf_c = lstm_cell(F.linear(torch.cat([x, vf_h.to(x.dtype)], -1), wc, bc), vf_c)
+                if defer:
+                    pi_h, pi_c = lstm_cell(deferred_linear(x, pi_h.to(x.dtype), wa, ba, bk_a, t), pi_c)
+                    vf_h, vf_c = lstm_cell(deferred_linear(x, vf_h.to(x.dtype), wc, bc, bk_c, t), vf_c)
+                else:
+                    pi_h, pi_c = lstm_cell(F.linear(torch.cat([x, pi_h.to(x.dtype)], -1), wa, ba), pi_c)
+                    vf_h, vf_c = lstm_cell(F.linear(torch.cat([x, vf_h.to(x.dtype)], -1), wc, bc), vf_c)
                 pi_hs.append(pi_h); vf_hs.append(vf_h)
             pi_seq, vf_seq = torch.stack(pi_hs), torch.stack(vf_hs)
-            mean = self.action_net(self.pi_net(pi_seq)).float()
-            values = self.value_net(self.vf_net(vf_seq)).float().squeeze(-1)
+            mean = linear(_run_seq(self.pi_net, pi_seq), self.action_net.weight, self.action_net.bias).float()
+            values = linear(_run_seq(self.vf_net, vf_seq), self.value_net.weight, self.value_net.bias).float().squeeze(-1)
         return values, self._log_prob(actions, mean), self.entropy()
 
     def predict_values(self, obs, states: RNNStates, episode_start):

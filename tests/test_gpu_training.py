@@ -206,3 +206,49 @@ def test_gaussian_head_statistics_and_logprob():
     _lib.check(lib.fdyn_gaussian_head(mean.data_ptr(), 1, log_std.data_ptr(), 1234, step.data_ptr(), 1, d.data_ptr(),
                                       lp.data_ptr(), B, _lib.current_stream()))
     assert torch.equal(d, mean.float())
+
+
+@pytest.mark.parametrize("dtype,tol", [(None, 2e-4), (torch.bfloat16, 6e-2)])
+def test_deferred_splitk_weight_gradients_match_plain_autograd(dtype, tol):
+    """The BPTT path with deferred / split-K weight gradients (fused.DeferredWgrad, fused.linear) against plain autograd
+    through F.linear on the same parameters and batch: every parameter gradient, relative to its norm."""
+    from hcrl_amd import fused
+    torch.manual_seed(3)
+    pol = RateLSTMPolicy(compute_dtype=dtype).cuda()
+    T, B = 6, 8192
+    obs = torch.randn(T, B, 18, device="cuda")
+    act = torch.randn(T, B, 4, device="cuda").clamp(-1, 1)
+    starts = (torch.rand(T, B, device="cuda") < 0.05).float()
+    st = pol.initial_state(B, "cuda")
+    st = type(st)(*[torch.randn_like(s) * 0.3 for s in st])
+    adv = torch.randn(T, B, device="cuda")
+
+    def grads(deferred, min_rows):
+        pol.deferred_wgrad = deferred
+        pol.zero_grad(set_to_none=True)
+        orig = fused.linear.__defaults__
+        fused.linear.__defaults__ = (min_rows,)
+        try:
+            v, lp, ent = pol.evaluate_sequence(obs, act, starts, st)
+            ((lp * adv).mean() + 0.5 * (v ** 2).mean() - 0.01 * ent).backward()
+        finally:
+            fused.linear.__defaults__ = orig
+        return {n: p.grad.detach().float().clone() for n, p in pol.named_parameters()}
+
+    plain, fast = grads(False, 1 << 60), grads(True, 8192)
+    assert set(plain) == set(fast)
+    for n in plain:
+        a, b = plain[n], fast[n]
+        err = float((a - b).norm() / (a.norm() + 1e-12))
+        assert err < tol, (n, err)
+    # flat-buffer gradients (FlatGrad: p.grad are views that autograd and the deferred flush must ADD into)
+    from hcrl_amd.ppo import FlatGrad
+    flat = FlatGrad(pol)
+    flat.zero()
+    pol.deferred_wgrad = True
+    v, lp, ent = pol.evaluate_sequence(obs, act, starts, st)
+    ((lp * adv).mean() + 0.5 * (v ** 2).mean() - 0.01 * ent).backward()
+    for n, p in pol.named_parameters():
+        assert p.grad.data_ptr() >= flat.buf.data_ptr() and p.grad.data_ptr() < flat.buf.data_ptr() + flat.buf.numel() * 4, n
+        err = float((p.grad.float() - fast[n]).norm() / (fast[n].norm() + 1e-12))
+        assert err < (1e-5 if dtype is None else 2e-2), (n, err)
