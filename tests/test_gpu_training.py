@@ -233,7 +233,7 @@ def test_deferred_splitk_weight_gradients_match_plain_autograd(dtype, tol):
             ((lp * adv).mean() + 0.5 * (v ** 2).mean() - 0.01 * ent).backward()
         finally:
             fused.linear.__defaults__ = orig
-        return {n: p.grad.detach().float().clone() for n, p in pol.named_parameters()}
+        return {n: p.grad.detach().float().clone() for n, p in pol.named_parameters() if p.grad is not None}   # zero-state W_hh: unused
 
     plain, fast = grads(False, 1 << 60), grads(True, 8192)
     assert set(plain) == set(fast)
@@ -249,6 +249,8 @@ def test_deferred_splitk_weight_gradients_match_plain_autograd(dtype, tol):
     v, lp, ent = pol.evaluate_sequence(obs, act, starts, st)
     ((lp * adv).mean() + 0.5 * (v ** 2).mean() - 0.01 * ent).backward()
     for n, p in pol.named_parameters():
+        if n not in fast:
+            continue
         assert p.grad.data_ptr() >= flat.buf.data_ptr() and p.grad.data_ptr() < flat.buf.data_ptr() + flat.buf.numel() * 4, n
         err = float((p.grad.float() - fast[n]).norm() / (fast[n].norm() + 1e-12))
         assert err < (1e-5 if dtype is None else 2e-2), (n, err)
