@@ -34,6 +34,8 @@ SIGNATURES = {
     "fdyn_rate_env_step_f32": (_i, _ENV_STEP),
     "fdyn_lstm_cell_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i64, _i, _p]),
     "fdyn_lstm_cell_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i64, _i, _p]),
+    "fdyn_lstm_seq_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i, _p]),
+    "fdyn_lstm_seq_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _i64, _i, _p]),
     "fdyn_lstm_cell_mfma": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _p]),
     "fdyn_gaussian_head": (_i, [_p, _i, _p, _u64, _p, _i, _p, _p, _i64, _p]),
     "fdyn_policy_heads": (_i, [_p, _p, _p, _p, _p, _p, _p, _u64, _p, _i, _p, _p, _p, _i64, _p]),

@@ -66,7 +66,10 @@ __device__ __forceinline__ float tanhf_(float x)
 template <typename GT>
 __global__ void __launch_bounds__(256)
 lstm_cell_fwd_kernel(const GT* __restrict__ gates, const float* __restrict__ c_prev, float* __restrict__ h_f32,
-                     GT* __restrict__ h_lp, float* __restrict__ c_out, GT* __restrict__ act_out, int64_t total_vec, int H)
+                     GT* __restrict__ h_lp, float* __restrict__ c_out, GT* __restrict__ act_out, int64_t total_vec, int H,
+                     const float* __restrict__ keep = nullptr /*[B]: c_prev *= keep (episode start)*/,
+                     GT* __restrict__ h_next = nullptr /*row stride next_stride: h * keep_next, the next step's input*/,
+                     int64_t next_stride = 0, const float* __restrict__ keep_next = nullptr)
 {
     const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (t >= total_vec) return;
@@ -79,6 +82,11 @@ lstm_cell_fwd_kernel(const GT* __restrict__ gates, const float* __restrict__ c_p
     Vec8<GT>::load(g0 + 2 * H, gg);
     Vec8<GT>::load(g0 + 3 * H, go);
     if (c_prev) { Vec8<GT>::load(g0 + H, gf); Vec8<float>::load(c_prev + row * H + j, cp); }
+    if (c_prev && keep) {
+        const float kp = keep[row];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) cp[k] *= kp;
+    }
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
         gi[k] = sigmoidf_(gi[k]); gg[k] = tanhf_(gg[k]); go[k] = sigmoidf_(go[k]);
@@ -89,6 +97,13 @@ lstm_cell_fwd_kernel(const GT* __restrict__ gates, const float* __restrict__ c_p
     if (c_out) Vec8<float>::store(c_out + row * H + j, c);
     if (h_f32) Vec8<float>::store(h_f32 + row * H + j, h);
     if (h_lp) Vec8<GT>::store(h_lp + row * H + j, h);
+    if (h_next) {
+        const float kn = keep_next ? keep_next[row] : 1.0f;
+        float hm[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) hm[k] = h[k] * kn;
+        Vec8<GT>::store(h_next + row * next_stride + j, hm);
+    }
     if (act_out) {
         GT* a0 = act_out + row * 4 * H + j;
         Vec8<GT>::store(a0, gi); Vec8<GT>::store(a0 + H, gf); Vec8<GT>::store(a0 + 2 * H, gg); Vec8<GT>::store(a0 + 3 * H, go);
@@ -98,9 +113,13 @@ lstm_cell_fwd_kernel(const GT* __restrict__ gates, const float* __restrict__ c_p
 // gradient of the cell update w.r.t. the pre-activation gates and c_prev
 template <typename GT>
 __global__ void __launch_bounds__(256)
-lstm_cell_bwd_kernel(const GT* __restrict__ act, const float* __restrict__ c_prev, const float* __restrict__ c_new,
-                     const GT* __restrict__ dh, const float* __restrict__ dc_next, GT* __restrict__ dgates,
-                     float* __restrict__ dc_prev, int64_t total_vec, int H)
+lstm_cell_bwd_kernel(const GT* act /*may alias dgates: every lane reads its 4 x 8 values before it writes them*/,
+                     const float* __restrict__ c_prev, const float* __restrict__ c_new,
+                     const GT* __restrict__ dh, const float* __restrict__ dc_next, GT* dgates,
+                     float* __restrict__ dc_prev, int64_t total_vec, int H,
+                     const float* __restrict__ keep = nullptr /*[B]: the forward used keep * c_prev*/,
+                     const GT* __restrict__ dh2 = nullptr /*second dh addend, row stride dh2_stride, scaled by dh2_keep*/,
+                     int64_t dh2_stride = 0, const float* __restrict__ dh2_keep = nullptr)
 {
     const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (t >= total_vec) return;
@@ -115,15 +134,24 @@ lstm_cell_bwd_kernel(const GT* __restrict__ act, const float* __restrict__ c_pre
     Vec8<GT>::load(dh + row * H + j, dhv);
     if (c_prev) Vec8<float>::load(c_prev + row * H + j, cp);
     if (dc_next) Vec8<float>::load(dc_next + row * H + j, dcn);
+    const float kp = keep ? keep[row] : 1.0f;
+    if (dh2) {                                            // recurrent gradient from step t + 1, summed in fp32
+        float d2[VEC];
+        Vec8<GT>::load(dh2 + row * dh2_stride + j, d2);
+        const float k2 = dh2_keep ? dh2_keep[row] : 1.0f;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) dhv[k] += k2 * d2[k];
+    }
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
+        if (c_prev) cp[k] *= kp;
         const float tc = tanhf_(cn[k]);
         const float dc = dhv[k] * ao[k] * (1.0f - tc * tc) + (dc_next ? dcn[k] : 0.0f);
         dov[k] = dhv[k] * tc * ao[k] * (1.0f - ao[k]);
         di[k] = dc * ag[k] * ai[k] * (1.0f - ai[k]);
         dg[k] = dc * ai[k] * (1.0f - ag[k] * ag[k]);
         df[k] = c_prev ? dc * cp[k] * af[k] * (1.0f - af[k]) : 0.0f;
-        dcp[k] = dc * af[k];
+        dcp[k] = dc * af[k] * kp;
     }
     GT* d0 = dgates + row * 4 * H + j;
     Vec8<GT>::store(d0, di); Vec8<GT>::store(d0 + H, df); Vec8<GT>::store(d0 + 2 * H, dg); Vec8<GT>::store(d0 + 3 * H, dov);
@@ -294,6 +322,43 @@ int fdyn_lstm_cell_bwd(const void* act, int bf16, const float* c_prev, const flo
     else
         hipLaunchKernelGGL((lstm_cell_bwd_kernel<float>), dim3(blocks(tv)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)act, c_prev, c_new, (const float*)dh, dc_next, (float*)dgates, dc_prev, tv, H);
+    return int(hipGetLastError());
+}
+
+int fdyn_lstm_seq_fwd(const void* gates, int gates_bf16, const float* c_prev, const float* keep, void* h_lp, float* c_out,
+                      void* act_out, void* h_next, int64_t next_stride, const float* keep_next, int64_t B, int H, void* stream)
+{
+    if (B < 0 || H <= 0 || H % VEC || (h_next && next_stride < H)) return FDYN_ERR_BAD_SIZE;
+    if (!gates || !c_prev || !h_lp || !c_out) return FDYN_ERR_NULL;
+    if (B == 0) return FDYN_OK;
+    const int64_t tv = B * (H / VEC);
+    if (gates_bf16)
+        hipLaunchKernelGGL((lstm_cell_fwd_kernel<uint16_t>), dim3(blocks(tv)), dim3(256), 0, (hipStream_t)stream,
+                           (const uint16_t*)gates, c_prev, (float*)nullptr, (uint16_t*)h_lp, c_out, (uint16_t*)act_out, tv, H, keep,
+                           (uint16_t*)h_next, next_stride, keep_next);
+    else
+        hipLaunchKernelGGL((lstm_cell_fwd_kernel<float>), dim3(blocks(tv)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)gates, c_prev, (float*)nullptr, (float*)h_lp, c_out, (float*)act_out, tv, H, keep,
+                           (float*)h_next, next_stride, keep_next);
+    return int(hipGetLastError());
+}
+
+int fdyn_lstm_seq_bwd(const void* act, int bf16, const float* c_prev, const float* keep, const float* c_new, const void* dh,
+                      const void* dh2, int64_t dh2_stride, const float* dh2_keep, const float* dc_next, void* dgates,
+                      float* dc_prev, int64_t B, int H, void* stream)
+{
+    if (B < 0 || H <= 0 || H % VEC || (dh2 && dh2_stride < H)) return FDYN_ERR_BAD_SIZE;
+    if (!act || !c_prev || !c_new || !dh || !dgates || !dc_prev) return FDYN_ERR_NULL;
+    if (B == 0) return FDYN_OK;
+    const int64_t tv = B * (H / VEC);
+    if (bf16)
+        hipLaunchKernelGGL((lstm_cell_bwd_kernel<uint16_t>), dim3(blocks(tv)), dim3(256), 0, (hipStream_t)stream,
+                           (const uint16_t*)act, c_prev, c_new, (const uint16_t*)dh, dc_next, (uint16_t*)dgates, dc_prev, tv, H, keep,
+                           (const uint16_t*)dh2, dh2_stride, dh2_keep);
+    else
+        hipLaunchKernelGGL((lstm_cell_bwd_kernel<float>), dim3(blocks(tv)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)act, c_prev, c_new, (const float*)dh, dc_next, (float*)dgates, dc_prev, tv, H, keep,
+                           (const float*)dh2, dh2_stride, dh2_keep);
     return int(hipGetLastError());
 }
 

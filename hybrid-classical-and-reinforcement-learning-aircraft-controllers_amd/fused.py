@@ -178,6 +178,80 @@ def deferred_linear(x: torch.Tensor, h: torch.Tensor, w: torch.Tensor, b: torch.
     return _DeferredLinearFn.apply(x, h, w, b, bucket, t)
 
 
+class _LSTMSequenceFn(torch.autograd.Function):
+    """A recurrent LSTM layer over T steps as ONE autograd node (BPTT inside).  Per step and direction: one GEMM and one
+    fused point-wise launch (fdyn_lstm_seq_fwd / _bwd: masks, recurrent add, next-input packing folded in); the weight and
+    bias gradients are one split-K GEMM / one reduction over all T*B rows at the end of the backward loop."""
+
+    @staticmethod
+    def forward(ctx, feats, w_ih, w_hh, b_ih, b_hh, h0, c0, keep):
+        lib = _lib.load()
+        T, B, kx = feats.shape
+        H = w_hh.shape[1]
+        K, dt, dev = kx + H, feats.dtype, feats.device
+        bf16 = dt == torch.bfloat16
+        assert bf16 or dt == torch.float32
+        assert w_ih.shape == (4 * H, kx) and w_hh.shape == (4 * H, H) and h0.shape == (B, H) and c0.shape == (B, H) and keep.shape == (T, B)
+        w = torch.cat([w_ih, w_hh], 1).to(dt)
+        b = (b_ih + b_hh).to(dt)
+        keep = keep.float().contiguous()
+        need = any(ctx.needs_input_grad[:5])
+        x_all = torch.empty((T, B, K), dtype=dt, device=dev)
+        x_all[:, :, :kx].copy_(feats)
+        x_all[0, :, kx:].copy_(h0.to(dt) * keep[0].unsqueeze(-1).to(dt))
+        act = torch.empty((T, B, 4 * H), dtype=dt, device=dev) if need else None
+        c_all = torch.empty((T + 1, B, H), dtype=torch.float32, device=dev)
+        c_all[0].copy_(c0)
+        h_seq = torch.empty((T, B, H), dtype=dt, device=dev)
+        st = _lib.current_stream()
+        for t in range(T):
+            gates = torch.nn.functional.linear(x_all[t], w, b)
+            last = t == T - 1
+            _lib.check(lib.fdyn_lstm_seq_fwd(gates.data_ptr(), int(bf16), c_all[t].data_ptr(), keep[t].data_ptr(), h_seq[t].data_ptr(),
+                                             c_all[t + 1].data_ptr(), act[t].data_ptr() if need else None,
+                                             None if last else x_all[t + 1].data_ptr() + kx * x_all.element_size(), K,
+                                             None if last else keep[t + 1].data_ptr(), B, H, st), "lstm_seq_fwd")
+        if need:
+            ctx.save_for_backward(x_all, act, c_all, keep, w)
+            ctx.kx, ctx.param_dtypes = kx, (w_ih.dtype, w_hh.dtype, b_ih.dtype, b_hh.dtype)
+        ctx.mark_non_differentiable(c_all)
+        return h_seq, c_all
+
+    @staticmethod
+    def backward(ctx, dh_seq, _dc_all):
+        lib = _lib.load()
+        x_all, act, c_all, keep, w = ctx.saved_tensors
+        T, B, K = x_all.shape
+        H, kx, dt, dev = c_all.shape[-1], ctx.kx, x_all.dtype, x_all.device
+        bf16 = dt == torch.bfloat16
+        dh_seq = dh_seq.to(dt).contiguous()
+        dcat = torch.empty((T, B, K), dtype=dt, device=dev)
+        dc = [torch.empty((B, H), dtype=torch.float32, device=dev) for _ in range(2)]
+        st = _lib.current_stream()
+        for t in range(T - 1, -1, -1):
+            last = t == T - 1
+            # dgates overwrite the saved activations in place: act becomes dY for the weight gradient below
+            _lib.check(lib.fdyn_lstm_seq_bwd(act[t].data_ptr(), int(bf16), c_all[t].data_ptr(), keep[t].data_ptr(), c_all[t + 1].data_ptr(),
+                                             dh_seq[t].data_ptr(), None if last else dcat[t + 1].data_ptr() + kx * dcat.element_size(), K,
+                                             None if last else keep[t + 1].data_ptr(), None if last else dc[(t + 1) & 1].data_ptr(),
+                                             act[t].data_ptr(), dc[t & 1].data_ptr(), B, H, st), "lstm_seq_bwd")
+            torch.mm(act[t], w, out=dcat[t])
+        dy = act.view(T * B, 4 * H)
+        dw = wgrad_splitk(dy, x_all.view(T * B, K)) if any(ctx.needs_input_grad[1:3]) else None
+        db = dy.sum(0, dtype=torch.float32) if any(ctx.needs_input_grad[3:5]) else None
+        d = ctx.param_dtypes
+        return (dcat[:, :, :kx] if ctx.needs_input_grad[0] else None,
+                dw[:, :kx].to(d[0]) if ctx.needs_input_grad[1] else None, dw[:, kx:].to(d[1]) if ctx.needs_input_grad[2] else None,
+                db.to(d[2]) if ctx.needs_input_grad[3] else None, db.to(d[3]) if ctx.needs_input_grad[4] else None,
+                None, None, None)
+
+
+def lstm_sequence(feats, w_ih, w_hh, b_ih, b_hh, h0, c0, keep):
+    """feats [T,B,kx] (compute dtype), parameters of one nn.LSTM layer, h0/c0 [B,H] (state before step 0, constants),
+    keep [T,B] (0 where an episode starts at that step) -> h_seq [T,B,H] (compute dtype), c_all [T+1,B,H] fp32."""
+    return _LSTMSequenceFn.apply(feats.contiguous(), w_ih, w_hh, b_ih, b_hh, h0, c0, keep)
+
+
 def gae(rewards, values, episode_starts, last_values, last_dones, gamma: float, lam: float):
     """[T, N] fp32 rollout -> advantages, returns; one HIP launch on the GPU."""
     T, N = rewards.shape

@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fused import DeferredWgrad, deferred_linear, linear, lstm_cell
+from .fused import DeferredWgrad, deferred_linear, linear, lstm_cell, lstm_sequence
 
 OBS_DIM, ACT_DIM = 18, 4
 
@@ -98,6 +98,7 @@ class RateLSTMPolicy(nn.Module):
         super().__init__()
         self.use_lstm, self.hidden, self.compute_dtype = use_lstm, policy_lstm_hidden, compute_dtype
         self.deferred_wgrad = True       # BPTT: one split-K weight-gradient GEMM per recurrent cell per backward pass
+        self.sequence_bptt = True        # BPTT: each recurrent cell over T steps is one autograd node (fused.lstm_sequence)
         if use_lstm:
             self.features_extractor = LSTMFeaturesExtractor(OBS_DIM, features_dim, lstm_hidden_size, n_lstm_layers)
             self.lstm_actor = nn.LSTM(features_dim, policy_lstm_hidden, 1)
@@ -285,10 +286,19 @@ class RateLSTMPolicy(nn.Module):
             la, lc = self.lstm_actor, self.lstm_critic
             wa, ba = torch.cat([la.weight_ih_l0, la.weight_hh_l0], 1), la.bias_ih_l0 + la.bias_hh_l0
             wc, bc = torch.cat([lc.weight_ih_l0, lc.weight_hh_l0], 1), lc.bias_ih_l0 + lc.bias_hh_l0
-            pi_hs, vf_hs = [], []
             pi_h, pi_c, vf_h, vf_c = states
-            # BPTT with deferred weight gradients (fused.DeferredWgrad): each step's backward only produces dX; dW / db of
-            # the two recurrent cells come from one split-K GEMM over all T*B rows when the backward pass ends
+            if self.sequence_bptt and feats.is_cuda:
+                # each recurrent cell over all T steps is ONE autograd node (fused.lstm_sequence): 2 launches per step
+                # and direction, weight gradients from one split-K GEMM over all T*B rows
+                keep_all = 1.0 - episode_starts.float()
+                pi_seq, _ = lstm_sequence(feats, la.weight_ih_l0, la.weight_hh_l0, la.bias_ih_l0, la.bias_hh_l0, pi_h, pi_c, keep_all)
+                vf_seq, _ = lstm_sequence(feats, lc.weight_ih_l0, lc.weight_hh_l0, lc.bias_ih_l0, lc.bias_hh_l0, vf_h, vf_c, keep_all)
+                mean = linear(_run_seq(self.pi_net, pi_seq), self.action_net.weight, self.action_net.bias).float()
+                values = linear(_run_seq(self.vf_net, vf_seq), self.value_net.weight, self.value_net.bias).float().squeeze(-1)
+                return values, self._log_prob(actions, mean), self.entropy()
+            pi_hs, vf_hs = [], []
+            # per-step autograd with deferred weight gradients (fused.DeferredWgrad): each step's backward only produces dX;
+            # dW / db of the two recurrent cells come from one split-K GEMM over all T*B rows when the backward pass ends
             defer = self.deferred_wgrad and feats.is_cuda and torch.is_grad_enabled()
             if defer:
                 Bn, kx, dt = feats.shape[1], feats.shape[2], feats.dtype

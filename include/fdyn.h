@@ -132,6 +132,17 @@ int fdyn_lstm_cell_fwd(const void* gates, int gates_bf16, const float* c_prev, f
                        void* act_out, int64_t B, int H, void* stream);
 int fdyn_lstm_cell_bwd(const void* act, int bf16, const float* c_prev, const float* c_new, const void* dh,
                        const float* dc_next, void* dgates, float* dc_prev, int64_t B, int H, void* stream);
+/* One step of an LSTM SEQUENCE (BPTT over T inside one autograd node): the same point-wise kernels with the episode-start
+ * masks and the recurrent plumbing folded in, so a step costs two launches each way (the GEMM and this).
+ * fwd: c_prev is multiplied by keep [B] (NULL = 1); besides h_lp [B][H] the kernel stores h * keep_next into h_next (row
+ *      stride next_stride elements: the recurrent columns of the NEXT step's [x | h] input row), or h_next = NULL.
+ * bwd: dh_total = dh + dh2_keep * dh2 (dh2 = the recurrent columns of step t+1's input gradient, row stride dh2_stride,
+ *      or NULL), summed in fp32; dgates may alias act (in place); dc_prev comes out already multiplied by keep.        */
+int fdyn_lstm_seq_fwd(const void* gates, int gates_bf16, const float* c_prev, const float* keep, void* h_lp, float* c_out,
+                      void* act_out, void* h_next, int64_t next_stride, const float* keep_next, int64_t B, int H, void* stream);
+int fdyn_lstm_seq_bwd(const void* act, int bf16, const float* c_prev, const float* keep, const float* c_new, const void* dh,
+                      const void* dh2, int64_t dh2_stride, const float* dh2_keep, const float* dc_next, void* dgates,
+                      float* dc_prev, int64_t B, int H, void* stream);
 /* The whole LSTM cell step as ONE MFMA kernel (csrc/lstm_mfma.hip): gates = [x | keep*h_prev] W^T + bias on
  * v_mfma_f32_32x32x16_bf16 with the gate non-linearity and cell update fused on the accumulators (no [B][4H] tensor).
  * x [B][kx] bf16, h_prev [B][kh] bf16, c_prev [B][H] fp32, keep [B] fp32 or NULL (0 = episode start: zero the state),

@@ -223,8 +223,8 @@ def test_deferred_splitk_weight_gradients_match_plain_autograd(dtype, tol):
     st = type(st)(*[torch.randn_like(s) * 0.3 for s in st])
     adv = torch.randn(T, B, device="cuda")
 
-    def grads(deferred, min_rows):
-        pol.deferred_wgrad = deferred
+    def grads(deferred, min_rows, sequence=False):
+        pol.deferred_wgrad, pol.sequence_bptt = deferred, sequence
         pol.zero_grad(set_to_none=True)
         orig = fused.linear.__defaults__
         fused.linear.__defaults__ = (min_rows,)
@@ -235,17 +235,18 @@ def test_deferred_splitk_weight_gradients_match_plain_autograd(dtype, tol):
             fused.linear.__defaults__ = orig
         return {n: p.grad.detach().float().clone() for n, p in pol.named_parameters() if p.grad is not None}   # zero-state W_hh: unused
 
-    plain, fast = grads(False, 1 << 60), grads(True, 8192)
-    assert set(plain) == set(fast)
+    plain, fast, seq = grads(False, 1 << 60), grads(True, 8192), grads(True, 8192, sequence=True)
+    assert set(plain) == set(fast) == set(seq)
     for n in plain:
-        a, b = plain[n], fast[n]
-        err = float((a - b).norm() / (a.norm() + 1e-12))
-        assert err < tol, (n, err)
+        for other in (fast, seq):                             # seq: the whole recurrence as one autograd node
+            a, b = plain[n], other[n]
+            err = float((a - b).norm() / (a.norm() + 1e-12))
+            assert err < tol, (n, err, other is seq)
     # flat-buffer gradients (FlatGrad: p.grad are views that autograd and the deferred flush must ADD into)
     from hcrl_amd.ppo import FlatGrad
     flat = FlatGrad(pol)
     flat.zero()
-    pol.deferred_wgrad = True
+    pol.deferred_wgrad, pol.sequence_bptt = True, False
     v, lp, ent = pol.evaluate_sequence(obs, act, starts, st)
     ((lp * adv).mean() + 0.5 * (v ** 2).mean() - 0.01 * ent).backward()
     for n, p in pol.named_parameters():
