@@ -105,9 +105,10 @@ def compute_gae(rewards, values, episode_starts, last_values, last_dones, gamma,
 
 class RecurrentPPO:
     def __init__(self, env, policy: Optional[RateLSTMPolicy] = None, config: Optional[PPOConfig] = None, seed: int = 0,
-                 use_graph: bool = True):
+                 use_graph: bool = True, use_update_graph: Optional[bool] = None):
         self.env, self.cfg = env, config or PPOConfig()
         self.use_graph, self._graph, self._graph_env = use_graph, None, None
+        self.use_update_graph = use_graph if use_update_graph is None else use_update_graph
         self.device = env.device
         torch.manual_seed(seed)                          # identical initial weights on every rank
         self.policy = (policy or RateLSTMPolicy()).to(self.device)
@@ -207,36 +208,92 @@ class RecurrentPPO:
         self.adv, self.ret = compute_gae(self.buf_rew, self.buf_val, self.buf_start, last_values, self.episode_start,
                                          cfg.gamma, cfg.gae_lambda)
 
+    def _minibatch_loss(self, obs, act, starts, adv, ret, old_logp, old_v, states):
+        """Clipped-surrogate PPO loss of one env slice ([T, mb] tensors) + the detached statistics."""
+        cfg, pol = self.cfg, self.policy
+        values, logp, entropy = pol.evaluate_sequence(obs, act, starts, states)
+        if cfg.normalize_advantage:
+            adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+        ratio = torch.exp(logp - old_logp)
+        pl = -torch.min(adv * ratio, adv * torch.clamp(ratio, 1 - cfg.clip_range, 1 + cfg.clip_range)).mean()
+        if cfg.clip_range_vf is not None:
+            values = old_v + torch.clamp(values - old_v, -cfg.clip_range_vf, cfg.clip_range_vf)
+        vl = torch.nn.functional.mse_loss(ret, values)
+        loss = pl + cfg.ent_coef * (-entropy) + cfg.vf_coef * vl
+        with torch.no_grad():
+            kl = ((ratio - 1) - (logp - old_logp)).mean()
+            cf = ((ratio - 1).abs() > cfg.clip_range).float().mean()
+        return loss, torch.stack([pl.detach(), vl.detach(), kl, cf])
+
+    def _build_update_graph(self, mb):
+        """Forward + loss + backward of one env slice as ONE hipGraph over static input buffers: the ~1500 launches of a
+        BPTT pass stop being paced by the host (at 16 384 envs the eager loop is launch-bound).  Gradients land in the
+        flat buffer; the collective, the clip and the optimizer step stay outside the graph."""
+        T, dev = self.cfg.n_steps, self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        g = {"obs": torch.zeros((T, mb, 18), **f32), "act": torch.zeros((T, mb, 4), **f32)}
+        for k in ("starts", "adv", "ret", "old_logp", "old_v"):
+            g[k] = torch.zeros((T, mb), **f32)
+        g["states"] = RNNStates(*[torch.zeros((mb, t.shape[1]), dtype=t.dtype, device=dev) for t in self.rollout_states])
+
+        def body():
+            self.flat.zero()
+            loss, st = self._minibatch_loss(g["obs"], g["act"], g["starts"], g["adv"], g["ret"], g["old_logp"], g["old_v"], g["states"])
+            loss.backward()
+            return st
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                     # warm-up: allocator, library handles, lazy one-time choices
+            for _ in range(2):
+                body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            g["stats"] = body()
+        g["graph"], g["mb"] = graph, mb
+        return g
+
     def update(self):
         cfg, pol = self.cfg, self.policy
         N = self.env.num_envs
         mb = max(1, N // cfg.n_minibatches)
         stats = dict(policy_loss=0.0, value_loss=0.0, approx_kl=0.0, clip_frac=0.0, grad_norm=0.0, n=0)
+        ug = None
+        if self.use_update_graph and self.device.type == "cuda":
+            ug = getattr(self, "_update_graph", None)
+            if ug is None or ug["mb"] != mb:
+                try:
+                    ug = self._update_graph = self._build_update_graph(mb)
+                except Exception as e:                    # capture is an optimisation: fall back to the eager loop, loudly
+                    print(f"[ppo] update-graph capture failed ({type(e).__name__}: {e}); running the update eagerly", flush=True)
+                    self.use_update_graph, ug = False, None
+                    torch.cuda.synchronize()
         for _ in range(cfg.n_epochs):
             perm = torch.randperm(N, device=self.device)
             for s in range(0, N - mb + 1, mb):
                 idx = perm[s:s + mb]
-                obs, act, starts = self.buf_obs[:, idx], self.buf_act[:, idx], self.buf_start[:, idx]
-                adv, ret, old_logp = self.adv[:, idx], self.ret[:, idx], self.buf_logp[:, idx]
-                values, logp, entropy = pol.evaluate_sequence(obs, act, starts, self.rollout_states.index(idx))
-                if cfg.normalize_advantage:
-                    adv = (adv - adv.mean()) / (adv.std() + 1e-8)
-                ratio = torch.exp(logp - old_logp)
-                pl = -torch.min(adv * ratio, adv * torch.clamp(ratio, 1 - cfg.clip_range, 1 + cfg.clip_range)).mean()
-                if cfg.clip_range_vf is not None:
-                    old_v = self.buf_val[:, idx]
-                    values = old_v + torch.clamp(values - old_v, -cfg.clip_range_vf, cfg.clip_range_vf)
-                vl = torch.nn.functional.mse_loss(ret, values)
-                loss = pl + cfg.ent_coef * (-entropy) + cfg.vf_coef * vl
-                self.flat.zero()
-                loss.backward()
+                if ug is not None:
+                    for k, src in (("obs", self.buf_obs), ("act", self.buf_act), ("starts", self.buf_start), ("adv", self.adv),
+                                   ("ret", self.ret), ("old_logp", self.buf_logp), ("old_v", self.buf_val)):
+                        torch.index_select(src, 1, idx, out=ug[k])
+                    for dst, src in zip(ug["states"], self.rollout_states):
+                        torch.index_select(src, 0, idx, out=dst)
+                    ug["graph"].replay()
+                    st = ug["stats"]
+                else:
+                    loss, st = self._minibatch_loss(self.buf_obs[:, idx], self.buf_act[:, idx], self.buf_start[:, idx],
+                                                    self.adv[:, idx], self.ret[:, idx], self.buf_logp[:, idx],
+                                                    self.buf_val[:, idx], self.rollout_states.index(idx))
+                    self.flat.zero()
+                    loss.backward()
                 self.flat.all_reduce_mean()                    # THE collective: one flat ~7.3 MB all-reduce
                 gn = self.flat.clip_norm_(cfg.max_grad_norm)
                 self.opt.step()
                 with torch.no_grad():
-                    stats["policy_loss"] += pl.detach(); stats["value_loss"] += vl.detach()
-                    stats["approx_kl"] += ((ratio - 1) - (logp - old_logp)).mean()
-                    stats["clip_frac"] += ((ratio - 1).abs() > cfg.clip_range).float().mean()
+                    stats["policy_loss"] += st[0]; stats["value_loss"] += st[1]
+                    stats["approx_kl"] += st[2]; stats["clip_frac"] += st[3]
                     stats["grad_norm"] += gn; stats["n"] += 1
         n = max(stats.pop("n"), 1)
         self.last_stats = {k: float(v.detach() if torch.is_tensor(v) else v) / n for k, v in stats.items()}

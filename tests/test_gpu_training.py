@@ -255,3 +255,26 @@ def test_deferred_splitk_weight_gradients_match_plain_autograd(dtype, tol):
         assert p.grad.data_ptr() >= flat.buf.data_ptr() and p.grad.data_ptr() < flat.buf.data_ptr() + flat.buf.numel() * 4, n
         err = float((p.grad.float() - fast[n]).norm() / (fast[n].norm() + 1e-12))
         assert err < (1e-5 if dtype is None else 2e-2), (n, err)
+
+
+def test_graphed_update_equals_eager_update():
+    """The PPO update with forward+backward replayed from a hipGraph over static slice buffers against the eager loop:
+    same rollout, same permutations, fp32 policy => the same parameters after two epochs (rounding of reordered sums only)."""
+    def run(graph):
+        env = GpuRateVecEnv(4096, "easy", 10.0, 0.02, "step", seed=11, precision="mixed", sampling="device")
+        m = RecurrentPPO(env, RateLSTMPolicy(), PPOConfig(n_steps=8, n_epochs=2, n_minibatches=2), seed=3,
+                         use_graph=False, use_update_graph=graph)
+        m.policy._noise_seed = 12345                         # the fused head's Philox key (drawn from the global RNG otherwise)
+        m.collect_rollout()
+        torch.manual_seed(99)                                # the slice permutations
+        st = m.update()
+        assert m.use_update_graph == graph                   # capture must not have fallen back
+        return [p.detach().clone() for p in m.policy.parameters()], st, m.buf_act.clone()
+
+    pe, se, ae = run(False)
+    pg, sg, ag = run(True)
+    assert torch.equal(ae, ag)                               # identical rollouts going in
+    for a, b in zip(pe, pg):
+        assert torch.allclose(a, b, atol=2e-5, rtol=1e-4), float((a - b).abs().max())
+    for k in se:
+        assert abs(se[k] - sg[k]) <= 1e-4 * max(1.0, abs(se[k])), (k, se[k], sg[k])
