@@ -258,23 +258,29 @@ def test_deferred_splitk_weight_gradients_match_plain_autograd(dtype, tol):
 
 
 def test_graphed_update_equals_eager_update():
-    """The PPO update with forward+backward replayed from a hipGraph over static slice buffers against the eager loop:
-    same rollout, same permutations, fp32 policy => the same parameters after two epochs (rounding of reordered sums only)."""
+    """The PPO update with forward+backward replayed from a hipGraph over static slice buffers against the eager loop on
+    the SAME rollout, parameters, optimizer state and slice permutations (fp32 policy): same parameters after two epochs."""
+    import copy
+    env = GpuRateVecEnv(4096, "easy", 10.0, 0.02, "step", seed=11, precision="mixed", sampling="device")
+    m = RecurrentPPO(env, RateLSTMPolicy(), PPOConfig(n_steps=8, n_epochs=2, n_minibatches=2), seed=3, use_graph=False)
+    m.collect_rollout()
+    p0 = copy.deepcopy(m.policy.state_dict())
+    o0 = copy.deepcopy(m.opt.state_dict())
+
     def run(graph):
-        env = GpuRateVecEnv(4096, "easy", 10.0, 0.02, "step", seed=11, precision="mixed", sampling="device")
-        m = RecurrentPPO(env, RateLSTMPolicy(), PPOConfig(n_steps=8, n_epochs=2, n_minibatches=2), seed=3,
-                         use_graph=False, use_update_graph=graph)
-        m.policy._noise_seed = 12345                         # the fused head's Philox key (drawn from the global RNG otherwise)
-        m.collect_rollout()
+        m.policy.load_state_dict(p0)
+        m.opt.load_state_dict(copy.deepcopy(o0))
+        m.use_update_graph = graph
         torch.manual_seed(99)                                # the slice permutations
         st = m.update()
         assert m.use_update_graph == graph                   # capture must not have fallen back
-        return [p.detach().clone() for p in m.policy.parameters()], st, m.buf_act.clone()
+        return [p.detach().clone() for p in m.policy.parameters()], st
 
-    pe, se, ae = run(False)
-    pg, sg, ag = run(True)
-    assert torch.equal(ae, ag)                               # identical rollouts going in
+    pe, se = run(False)
+    pg, sg = run(True)
+    moved = max(float((a - b).abs().max()) for a, b in zip(pe, p0.values()) if a.shape == b.shape)
+    assert moved > 1e-4                                      # the update did something
     for a, b in zip(pe, pg):
-        assert torch.allclose(a, b, atol=2e-5, rtol=1e-4), float((a - b).abs().max())
+        assert torch.allclose(a, b, atol=5e-5, rtol=1e-3), float((a - b).abs().max())
     for k in se:
-        assert abs(se[k] - sg[k]) <= 1e-4 * max(1.0, abs(se[k])), (k, se[k], sg[k])
+        assert abs(se[k] - sg[k]) <= 1e-3 * max(1.0, abs(se[k])), (k, se[k], sg[k])
