@@ -27,6 +27,7 @@ __device__ __forceinline__ uint16_t f2bf(float f)
 
 template <typename T> struct Vec8;
 template <> struct Vec8<float> {
+    static __device__ __forceinline__ float scalar(float v) { return v; }
     static __device__ __forceinline__ void load(const float* p, float (&o)[VEC])
     {
         const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
@@ -39,6 +40,7 @@ template <> struct Vec8<float> {
     }
 };
 template <> struct Vec8<uint16_t> {   // bf16 storage
+    static __device__ __forceinline__ float scalar(uint16_t v) { return __uint_as_float(uint32_t(v) << 16); }
     static __device__ __forceinline__ void load(const uint16_t* p, float (&o)[VEC])
     {
         const uint4 a = *reinterpret_cast<const uint4*>(p);
@@ -287,6 +289,134 @@ policy_heads_kernel(const uint16_t* __restrict__ pi_hidden /*[B][64] bf16*/, con
     value[i] = val;
 }
 
+
+// ---- reductions of the PPO update ---------------------------------------------------------------------------------------
+// Written here rather than left to the framework's generic reductions for two reasons: they are few, large and fixed in
+// shape (column sums of [T*B][N] gradient blocks, and the scalar sums of the clipped-surrogate loss), and the update is
+// replayed from a hipGraph, where every kernel must be self-contained (the accumulators are cleared by a kernel of the
+// same launch sequence, not by a memset node).
+__global__ void zero_f32_kernel(float* __restrict__ p, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.0f;
+}
+
+// out[c] += sum over a tile of rows of x[r][c]  (x row-major [M][N]); one block = ROWS_PER_BLOCK rows x all columns
+constexpr int COLSUM_ROWS = 256;
+template <typename GT>
+__global__ void __launch_bounds__(256)
+colsum_kernel(const GT* __restrict__ x, int64_t M, int N, float* __restrict__ out)
+{
+    const int64_t r0 = int64_t(blockIdx.x) * COLSUM_ROWS;
+    const int64_t r1 = r0 + COLSUM_ROWS < M ? r0 + COLSUM_ROWS : M;
+    for (int c = threadIdx.x; c < N; c += blockDim.x) {
+        float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
+        int64_t r = r0;
+        for (; r + 3 < r1; r += 4) {                        // four independent loads in flight per lane
+            acc0 += Vec8<GT>::scalar(x[r * N + c]);
+            acc1 += Vec8<GT>::scalar(x[(r + 1) * N + c]);
+            acc2 += Vec8<GT>::scalar(x[(r + 2) * N + c]);
+            acc3 += Vec8<GT>::scalar(x[(r + 3) * N + c]);
+        }
+        for (; r < r1; ++r) acc0 += Vec8<GT>::scalar(x[r * N + c]);
+        atomicAdd(out + c, (acc0 + acc1) + (acc2 + acc3));
+    }
+}
+
+// ws[0] += sum adv, ws[1] += sum adv^2
+__global__ void __launch_bounds__(256)
+adv_moments_kernel(const float* __restrict__ adv, int64_t M, float* __restrict__ ws)
+{
+    __shared__ float s0[256], s1[256];
+    float a = 0.0f, b = 0.0f;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < M; i += int64_t(gridDim.x) * blockDim.x) {
+        const float v = adv[i];
+        a += v; b += v * v;
+    }
+    s0[threadIdx.x] = a; s1[threadIdx.x] = b;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) { s0[threadIdx.x] += s0[threadIdx.x + w]; s1[threadIdx.x] += s1[threadIdx.x + w]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { atomicAdd(ws + 0, s0[0]); atomicAdd(ws + 1, s1[0]); }
+}
+
+// Clipped-surrogate PPO loss of one slice and its gradient w.r.t. the policy outputs, one lane per (t, env) sample.
+// stats: [0] policy loss, [1] value loss, [2] approx KL, [3] clip fraction, [4] total loss (all means over M; the
+// entropy term is added by the host from log_std), [5..8] d loss / d log_std (the log-prob part).
+// Semantics: learned_controllers/train_rate.py drives SB3's PPO.train -- ratio = exp(logp - old_logp), advantages
+// normalised with the unbiased std, -min(A r, A clip(r)), mse value loss, KL estimate mean((r - 1) - log r).
+__global__ void __launch_bounds__(256)
+ppo_loss_kernel(const float* __restrict__ mean /*[M][4]*/, const float* __restrict__ actions /*[M][4]*/,
+                const float* __restrict__ log_std /*[4]*/, const float* __restrict__ values, const float* __restrict__ old_logp,
+                const float* __restrict__ adv, const float* __restrict__ ret, const float* __restrict__ old_values,
+                const float* __restrict__ ws /*[2] adv moments*/, int normalize_adv, float clip_range, float clip_range_vf,
+                float vf_coef, int64_t M, float* __restrict__ dmean /*[M][4]*/, float* __restrict__ dvalues /*[M]*/,
+                float* __restrict__ stats /*[9]*/)
+{
+    __shared__ float red[9][256];
+    const float inv_m = 1.0f / float(M);
+    float a_mean = 0.0f, a_scale = 1.0f;
+    if (normalize_adv) {
+        a_mean = ws[0] * inv_m;
+        const float var = (ws[1] - float(M) * a_mean * a_mean) / float(M > 1 ? M - 1 : 1);      // torch.std: unbiased
+        a_scale = 1.0f / (sqrtf(var > 0.0f ? var : 0.0f) + 1e-8f);
+    }
+    float ls[4], iv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ls[k] = log_std[k]; iv[k] = __expf(-2.0f * ls[k]); }
+    float acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.0f;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < M; i += int64_t(gridDim.x) * blockDim.x) {
+        const float4 mu = reinterpret_cast<const float4*>(mean)[i], ac = reinterpret_cast<const float4*>(actions)[i];
+        const float d[4] = { ac.x - mu.x, ac.y - mu.y, ac.z - mu.z, ac.w - mu.w };
+        float logp = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) logp += -0.5f * d[k] * d[k] * iv[k] - ls[k] - 0.9189385332046727f;
+        const float lr = logp - old_logp[i];
+        const float r = __expf(lr);
+        const float A = (adv[i] - a_mean) * a_scale;
+        const float rc = fminf(fmaxf(r, 1.0f - clip_range), 1.0f + clip_range);
+        const float s1 = A * r, s2 = A * rc;
+        const float g_logp = (s1 <= s2) ? -A * r * inv_m : 0.0f;          // d(-min(s1, s2)) / d logp
+        float v = values[i];
+        float dv_scale = 1.0f;
+        if (clip_range_vf > 0.0f) {                                       // values = old + clip(values - old)
+            const float ov = old_values[i], dvv = v - ov;
+            dv_scale = (dvv >= -clip_range_vf && dvv <= clip_range_vf) ? 1.0f : 0.0f;
+            v = ov + fminf(fmaxf(dvv, -clip_range_vf), clip_range_vf);
+        }
+        const float ev = v - ret[i];
+        dvalues[i] = vf_coef * 2.0f * ev * inv_m * dv_scale;
+        float4 gm;
+        gm.x = g_logp * d[0] * iv[0]; gm.y = g_logp * d[1] * iv[1]; gm.z = g_logp * d[2] * iv[2]; gm.w = g_logp * d[3] * iv[3];
+        reinterpret_cast<float4*>(dmean)[i] = gm;
+        acc[0] += -fminf(s1, s2); acc[1] += ev * ev; acc[2] += (r - 1.0f) - lr; acc[3] += (fabsf(r - 1.0f) > clip_range) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[5 + k] += g_logp * (d[k] * d[k] * iv[k] - 1.0f);
+    }
+    acc[4] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) red[k][threadIdx.x] = acc[k];
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 9) {
+        const int k = threadIdx.x;
+        float v = red[k][0];
+        if (k < 4) v *= inv_m;                                              // means; [5..8] already carry 1/M through g_logp
+        if (k == 4) v = (red[0][0] + vf_coef * red[1][0]) * inv_m;          // policy + vf_coef * value part of the loss
+        atomicAdd(stats + k, v);
+    }
+}
+
 inline unsigned blocks(int64_t n) { return unsigned((n + 255) / 256); }
 
 }  // namespace
@@ -359,6 +489,37 @@ int fdyn_lstm_seq_bwd(const void* act, int bf16, const float* c_prev, const floa
         hipLaunchKernelGGL((lstm_cell_bwd_kernel<float>), dim3(blocks(tv)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)act, c_prev, c_new, (const float*)dh, dc_next, (float*)dgates, dc_prev, tv, H, keep,
                            (const float*)dh2, dh2_stride, dh2_keep);
+    return int(hipGetLastError());
+}
+
+int fdyn_colsum(const void* x, int bf16, int64_t M, int N, float* out, void* stream)
+{
+    if (M < 0 || N <= 0) return FDYN_ERR_BAD_SIZE;
+    if (!out || (M > 0 && !x)) return FDYN_ERR_NULL;
+    hipLaunchKernelGGL(zero_f32_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, N);
+    if (M > 0) {
+        const unsigned nb = unsigned((M + COLSUM_ROWS - 1) / COLSUM_ROWS);
+        if (bf16) hipLaunchKernelGGL((colsum_kernel<uint16_t>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, M, N, out);
+        else hipLaunchKernelGGL((colsum_kernel<float>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)x, M, N, out);
+    }
+    return int(hipGetLastError());
+}
+
+int fdyn_ppo_loss(const float* mean, const float* actions, const float* log_std, const float* values, const float* old_logp,
+                  const float* adv, const float* ret, const float* old_values, int normalize_adv, float clip_range,
+                  float clip_range_vf, float vf_coef, int64_t M, float* dmean, float* dvalues, float* stats /*[FDYN_PPO_NSTATS]*/,
+                  float* ws /*[2]*/, void* stream)
+{
+    if (M <= 0) return FDYN_ERR_BAD_SIZE;
+    if (!mean || !actions || !log_std || !values || !old_logp || !adv || !ret || !dmean || !dvalues || !stats || !ws ||
+        (clip_range_vf > 0.0f && !old_values)) return FDYN_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(zero_f32_kernel, dim3(1), dim3(256), 0, st, stats, FDYN_PPO_NSTATS);
+    hipLaunchKernelGGL(zero_f32_kernel, dim3(1), dim3(256), 0, st, ws, 2);
+    const unsigned nb = unsigned(M / 256 < 1 ? 1 : (M / 256 > 1024 ? 1024 : M / 256));
+    if (normalize_adv) hipLaunchKernelGGL(adv_moments_kernel, dim3(nb), dim3(256), 0, st, adv, M, ws);
+    hipLaunchKernelGGL(ppo_loss_kernel, dim3(nb), dim3(256), 0, st, mean, actions, log_std, values, old_logp, adv, ret, old_values,
+                       ws, normalize_adv, clip_range, clip_range_vf, vf_coef, M, dmean, dvalues, stats);
     return int(hipGetLastError());
 }
 

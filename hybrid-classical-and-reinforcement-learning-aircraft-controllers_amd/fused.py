@@ -71,6 +71,26 @@ def lstm_cell(gates: torch.Tensor, c_prev: Optional[torch.Tensor]) -> Tuple[torc
 _BMM_F32_OUT = None
 
 
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    """x [M, N] (bf16 / fp32, contiguous) -> fp32 [N] column sums (bias gradients): hand-written HIP reduction on the GPU
+    (graph-replay safe, unlike the generic multi-block reductions on this stack), plain torch on the CPU."""
+    if not x.is_cuda:
+        return x.sum(0, dtype=torch.float32)
+    x = x.contiguous()
+    M, N = x.shape
+    out = torch.empty(N, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().fdyn_colsum(x.data_ptr(), int(x.dtype == torch.bfloat16), M, N, out.data_ptr(), _lib.current_stream()),
+               "colsum")
+    return out
+
+
+def _sum_parts(part: torch.Tensor) -> torch.Tensor:
+    """part [S, N, K] fp32 -> sum over S as a [1, S] x [S, N*K] GEMM (no generic reduction kernel)."""
+    S, N, K = part.shape
+    ones = torch.ones((1, S), dtype=part.dtype, device=part.device)
+    return torch.mm(ones, part.view(S, N * K)).view(N, K)
+
+
 def wgrad_splitk(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     """dy [M, N], x [M, K] (same dtype) -> dy^T x as fp32 [N, K]."""
     global _BMM_F32_OUT
@@ -87,10 +107,10 @@ def wgrad_splitk(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
         try:                                              # fp32 partials straight from the MFMA accumulators
             part = torch.bmm(a, b, out_dtype=torch.float32)
             _BMM_F32_OUT = True
-            return part.sum(0)
+            return _sum_parts(part)
         except (TypeError, RuntimeError):
             _BMM_F32_OUT = False
-    return torch.bmm(a, b).sum(0, dtype=torch.float32)
+    return _sum_parts(torch.bmm(a, b).float())
 
 
 class _SplitKLinearFn(torch.autograd.Function):
@@ -109,7 +129,7 @@ class _SplitKLinearFn(torch.autograd.Function):
         dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
         dx = (dy2 @ w.to(dy.dtype)).view_as(x) if ctx.needs_input_grad[0] else None
         dw = wgrad_splitk(dy2.contiguous(), x2.contiguous()).to(w.dtype) if ctx.needs_input_grad[1] else None
-        db = dy2.sum(0, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        db = colsum(dy2) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db
 
 
@@ -140,7 +160,7 @@ class DeferredWgrad:
         N = self.dy.shape[-1]
         dy = self.dy.view(T * B, N)
         dw = wgrad_splitk(dy, self.x.view(T * B, K))
-        db = dy.sum(0, dtype=torch.float32)
+        db = colsum(dy)
         for p, cols in self.sinks:
             g = dw if cols is None else dw[:, cols]
             p.grad = g.to(p.dtype).clone() if p.grad is None else p.grad.add_(g.to(p.dtype))
@@ -238,7 +258,7 @@ class _LSTMSequenceFn(torch.autograd.Function):
             torch.mm(act[t], w, out=dcat[t])
         dy = act.view(T * B, 4 * H)
         dw = wgrad_splitk(dy, x_all.view(T * B, K)) if any(ctx.needs_input_grad[1:3]) else None
-        db = dy.sum(0, dtype=torch.float32) if any(ctx.needs_input_grad[3:5]) else None
+        db = colsum(dy) if any(ctx.needs_input_grad[3:5]) else None
         d = ctx.param_dtypes
         return (dcat[:, :, :kx] if ctx.needs_input_grad[0] else None,
                 dw[:, :kx].to(d[0]) if ctx.needs_input_grad[1] else None, dw[:, kx:].to(d[1]) if ctx.needs_input_grad[2] else None,
@@ -250,6 +270,69 @@ def lstm_sequence(feats, w_ih, w_hh, b_ih, b_hh, h0, c0, keep):
     """feats [T,B,kx] (compute dtype), parameters of one nn.LSTM layer, h0/c0 [B,H] (state before step 0, constants),
     keep [T,B] (0 where an episode starts at that step) -> h_seq [T,B,H] (compute dtype), c_all [T+1,B,H] fp32."""
     return _LSTMSequenceFn.apply(feats.contiguous(), w_ih, w_hh, b_ih, b_hh, h0, c0, keep)
+
+
+class _PPOLossFn(torch.autograd.Function):
+    """Clipped-surrogate PPO loss of one slice, forward and gradient in one fused launch (fdyn_ppo_loss)."""
+
+    @staticmethod
+    def forward(ctx, mean, values, log_std, actions, old_logp, adv, ret, old_values, normalize_adv, clip_range, clip_range_vf,
+                vf_coef, ent_coef):
+        lib = _lib.load()
+        f = lambda t: t.detach().float().contiguous()                     # noqa: E731
+        mean_, values_, actions_, old_logp_, adv_, ret_ = f(mean), f(values), f(actions), f(old_logp), f(adv), f(ret)
+        M = values_.numel()
+        assert mean_.numel() == 4 * M and actions_.numel() == 4 * M and old_logp_.numel() == M and adv_.numel() == M and ret_.numel() == M
+        ov = f(old_values) if clip_range_vf is not None else None
+        dev = mean_.device
+        dmean, dvalues = torch.empty_like(mean_), torch.empty_like(values_)
+        stats = torch.empty(9, dtype=torch.float32, device=dev)
+        ws = torch.empty(2, dtype=torch.float32, device=dev)
+        ls = f(log_std)
+        _lib.check(lib.fdyn_ppo_loss(mean_.data_ptr(), actions_.data_ptr(), ls.data_ptr(), values_.data_ptr(), old_logp_.data_ptr(),
+                                     adv_.data_ptr(), ret_.data_ptr(), _lib.ptr(ov), int(bool(normalize_adv)), float(clip_range),
+                                     float(clip_range_vf) if clip_range_vf is not None else -1.0, float(vf_coef), M,
+                                     dmean.data_ptr(), dvalues.data_ptr(), stats.data_ptr(), ws.data_ptr(), _lib.current_stream()),
+                   "ppo_loss")
+        # entropy of the diagonal Gaussian: sum_k (0.5 + 0.5 log 2 pi + log_std_k); loss += ent_coef * (-entropy)
+        entropy = 4 * 1.4189385332046727 + ((ls[0] + ls[1]) + (ls[2] + ls[3]))
+        loss = stats[4] - ent_coef * entropy
+        ctx.save_for_backward(dmean, dvalues, stats[5:9] - ent_coef)
+        ctx.shapes = (mean.shape, values.shape, mean.dtype, values.dtype, log_std.dtype)
+        ctx.mark_non_differentiable(stats)
+        return loss, stats
+
+    @staticmethod
+    def backward(ctx, g, _gs):
+        dmean, dvalues, dls = ctx.saved_tensors
+        ms, vs, md, vd, ld = ctx.shapes
+        return ((dmean * g).view(ms).to(md), (dvalues * g).view(vs).to(vd), (dls * g).to(ld)) + (None,) * 10
+
+
+def ppo_loss(mean, values, log_std, actions, old_logp, adv, ret, old_values, normalize_adv, clip_range, clip_range_vf, vf_coef,
+             ent_coef):
+    """-> (loss, stats[4] = policy loss, value loss, approx KL, clip fraction).  Fused HIP kernel on the GPU; the CPU path
+    (unit tests, gloo rehearsals) is the same arithmetic in torch ops."""
+    if mean.is_cuda:
+        loss, st = _PPOLossFn.apply(mean, values, log_std, actions, old_logp, adv, ret, old_values, normalize_adv, clip_range,
+                                    clip_range_vf, vf_coef, ent_coef)
+        return loss, st[:4]
+    import math
+    var = (2 * log_std).exp()
+    logp = (-((actions - mean) ** 2) / (2 * var) - log_std - 0.5 * math.log(2 * math.pi)).sum(-1)
+    if normalize_adv:
+        adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+    ratio = torch.exp(logp - old_logp)
+    pl = -torch.min(adv * ratio, adv * torch.clamp(ratio, 1 - clip_range, 1 + clip_range)).mean()
+    if clip_range_vf is not None:
+        values = old_values + torch.clamp(values - old_values, -clip_range_vf, clip_range_vf)
+    vl = torch.nn.functional.mse_loss(ret, values)
+    entropy = (0.5 + 0.5 * math.log(2 * math.pi) + log_std).sum()
+    loss = pl + ent_coef * (-entropy) + vf_coef * vl
+    with torch.no_grad():
+        kl = ((ratio - 1) - (logp - old_logp)).mean()
+        cf = ((ratio - 1).abs() > clip_range).float().mean()
+    return loss, torch.stack([pl.detach(), vl.detach(), kl, cf])
 
 
 def gae(rewards, values, episode_starts, last_values, last_dones, gamma: float, lam: float):

@@ -272,15 +272,19 @@ class RateLSTMPolicy(nn.Module):
     # ---- sequence evaluation (PPO update, BPTT over T) ----------------------------------------------------------
     def evaluate_sequence(self, obs, actions, episode_starts, states: RNNStates) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """obs [T,B,18], actions [T,B,4], episode_starts [T,B], states at t=0 -> values [T,B], log_probs [T,B], entropy."""
+        values, mean = self.sequence_heads(obs, episode_starts, states)
+        return values, self._log_prob(actions, mean), self.entropy()
+
+    def sequence_heads(self, obs, episode_starts, states: RNNStates) -> Tuple[torch.Tensor, torch.Tensor]:
+        """BPTT forward over T steps: obs [T,B,18], episode_starts [T,B], states at t=0 -> values [T,B], action means [T,B,4]."""
         T = obs.shape[0]
-        values, logps = [], []
         with torch.autocast(obs.device.type, dtype=self.compute_dtype, enabled=self.compute_dtype is not None):
             if not self.use_lstm:
                 flat = obs.reshape(-1, OBS_DIM)
                 lat_pi, lat_vf = _run_seq(self.pi_net, flat), _run_seq(self.vf_net, flat)
                 mean = linear(lat_pi, self.action_net.weight, self.action_net.bias).float().view(T, -1, ACT_DIM)
                 values = linear(lat_vf, self.value_net.weight, self.value_net.bias).float().view(T, -1)
-                return values, self._log_prob(actions, mean), self.entropy()
+                return values, mean
             # the zero-state feature extractor has no time dependence: run it for all T*B rows in one set of GEMMs
             feats = self.features_extractor(obs.reshape(-1, OBS_DIM)).view(T, -1, self.features_extractor.features_dim)
             la, lc = self.lstm_actor, self.lstm_critic
@@ -295,7 +299,7 @@ class RateLSTMPolicy(nn.Module):
                 vf_seq, _ = lstm_sequence(feats, lc.weight_ih_l0, lc.weight_hh_l0, lc.bias_ih_l0, lc.bias_hh_l0, vf_h, vf_c, keep_all)
                 mean = linear(_run_seq(self.pi_net, pi_seq), self.action_net.weight, self.action_net.bias).float()
                 values = linear(_run_seq(self.vf_net, vf_seq), self.value_net.weight, self.value_net.bias).float().squeeze(-1)
-                return values, self._log_prob(actions, mean), self.entropy()
+                return values, mean
             pi_hs, vf_hs = [], []
             # per-step autograd with deferred weight gradients (fused.DeferredWgrad): each step's backward only produces dX;
             # dW / db of the two recurrent cells come from one split-K GEMM over all T*B rows when the backward pass ends
@@ -322,7 +326,7 @@ class RateLSTMPolicy(nn.Module):
             pi_seq, vf_seq = torch.stack(pi_hs), torch.stack(vf_hs)
             mean = linear(_run_seq(self.pi_net, pi_seq), self.action_net.weight, self.action_net.bias).float()
             values = linear(_run_seq(self.vf_net, vf_seq), self.value_net.weight, self.value_net.bias).float().squeeze(-1)
-        return values, self._log_prob(actions, mean), self.entropy()
+        return values, mean
 
     def predict_values(self, obs, states: RNNStates, episode_start):
         return self.step(obs, states, episode_start, deterministic=True)[1]

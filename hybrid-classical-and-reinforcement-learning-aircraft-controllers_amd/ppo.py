@@ -21,6 +21,7 @@ from typing import Optional
 import torch
 import torch.distributed as dist
 
+from .fused import ppo_loss
 from .policy import RateLSTMPolicy, RNNStates
 
 
@@ -211,19 +212,9 @@ class RecurrentPPO:
     def _minibatch_loss(self, obs, act, starts, adv, ret, old_logp, old_v, states):
         """Clipped-surrogate PPO loss of one env slice ([T, mb] tensors) + the detached statistics."""
         cfg, pol = self.cfg, self.policy
-        values, logp, entropy = pol.evaluate_sequence(obs, act, starts, states)
-        if cfg.normalize_advantage:
-            adv = (adv - adv.mean()) / (adv.std() + 1e-8)
-        ratio = torch.exp(logp - old_logp)
-        pl = -torch.min(adv * ratio, adv * torch.clamp(ratio, 1 - cfg.clip_range, 1 + cfg.clip_range)).mean()
-        if cfg.clip_range_vf is not None:
-            values = old_v + torch.clamp(values - old_v, -cfg.clip_range_vf, cfg.clip_range_vf)
-        vl = torch.nn.functional.mse_loss(ret, values)
-        loss = pl + cfg.ent_coef * (-entropy) + cfg.vf_coef * vl
-        with torch.no_grad():
-            kl = ((ratio - 1) - (logp - old_logp)).mean()
-            cf = ((ratio - 1).abs() > cfg.clip_range).float().mean()
-        return loss, torch.stack([pl.detach(), vl.detach(), kl, cf])
+        values, mean = pol.sequence_heads(obs, starts, states)
+        return ppo_loss(mean, values, pol.log_std, act, old_logp, adv, ret, old_v, cfg.normalize_advantage, cfg.clip_range,
+                        cfg.clip_range_vf, cfg.vf_coef, cfg.ent_coef)
 
     def _build_update_graph(self, mb):
         """Forward + loss + backward of one env slice as ONE hipGraph over static input buffers: the ~1500 launches of a
@@ -261,7 +252,7 @@ class RecurrentPPO:
         mb = max(1, N // cfg.n_minibatches)
         stats = dict(policy_loss=0.0, value_loss=0.0, approx_kl=0.0, clip_frac=0.0, grad_norm=0.0, n=0)
         ug = None
-        if self.use_update_graph and self.device.type == "cuda":
+        if self.use_update_graph and self.device.type == "cuda" and (pol.sequence_bptt or not pol.use_lstm):
             ug = getattr(self, "_update_graph", None)
             if ug is None or ug["mb"] != mb:
                 try:

@@ -284,3 +284,66 @@ def test_graphed_update_equals_eager_update():
         assert torch.allclose(a, b, atol=5e-5, rtol=1e-3), float((a - b).abs().max())
     for k in se:
         assert abs(se[k] - sg[k]) <= 1e-3 * max(1.0, abs(se[k])), (k, se[k], sg[k])
+
+
+def test_fused_ppo_loss_and_colsum_match_torch():
+    """fdyn_ppo_loss (loss, statistics, gradients w.r.t. action means / values / log_std) against the same arithmetic in
+    plain torch ops on the CPU in fp64-free fp32; fdyn_colsum against torch.sum."""
+    from hcrl_amd import fused
+    torch.manual_seed(0)
+    T, B = 16, 4096
+    mean = torch.randn(T, B, 4, device="cuda") * 0.3
+    act = (mean + 0.5 * torch.randn_like(mean)).clamp(-1, 1)
+    log_std = torch.tensor([-0.7, -0.2, 0.1, -1.0], device="cuda")
+    values, ret = torch.randn(T, B, device="cuda"), torch.randn(T, B, device="cuda")
+    adv = torch.randn(T, B, device="cuda") * 3 + 0.5
+    old_v = values + 0.3 * torch.randn_like(values)
+    with torch.no_grad():
+        var = (2 * log_std).exp()
+        old_logp = (-((act - mean) ** 2) / (2 * var) - log_std - 0.9189385332).sum(-1) + 0.2 * torch.randn(T, B, device="cuda")
+    for clip_vf in (None, 0.2):
+        outs = []
+        for dev in ("cuda", "cpu"):
+            m, v, ls = (t.to(dev).clone().requires_grad_(True) for t in (mean, values, log_std))
+            loss, st = fused.ppo_loss(m, v, ls, act.to(dev), old_logp.to(dev), adv.to(dev), ret.to(dev), old_v.to(dev), True, 0.2,
+                                      clip_vf, 0.5, 0.01)
+            loss.backward()
+            outs.append([t.detach().cpu() for t in (loss, st, m.grad, v.grad, ls.grad)])
+        for a, b, name in zip(outs[0], outs[1], ("loss", "stats", "dmean", "dvalues", "dlog_std")):
+            assert torch.allclose(a, b, rtol=2e-4, atol=2e-6 if name.startswith("d") else 2e-5), (name, clip_vf, float((a - b).abs().max()))
+    for dt in (torch.float32, torch.bfloat16):
+        x = torch.randn(70001, 384, device="cuda").to(dt)
+        got, want = fused.colsum(x), x.double().sum(0)
+        assert float((got.double() - want).abs().max()) < 2e-2
+
+
+def test_update_graph_replays_match_eager_at_training_size():
+    """Six replays of the captured forward+backward on fresh slices (16 384 envs x 64 steps, bf16 policy) against the eager
+    pass on the same static buffers: every parameter gradient and the loss statistics.  (Guards the graph path against
+    stale / uninitialised reductions under replay.)"""
+    env = GpuRateVecEnv(16384, "easy", 10.0, 0.02, "step", seed=42, precision="mixed", sampling="device")
+    m = RecurrentPPO(env, RateLSTMPolicy(compute_dtype=torch.bfloat16), PPOConfig(n_steps=64, n_epochs=1, n_minibatches=8,
+                                                                                  reward_scale=0.02), seed=42, use_graph=False)
+    m.collect_rollout()
+    N, mb = 16384, 2048
+    ug = m._build_update_graph(mb)
+    for trial in range(6):
+        idx = torch.randperm(N, device="cuda")[:mb]
+        for k, src in (("obs", m.buf_obs), ("act", m.buf_act), ("starts", m.buf_start), ("adv", m.adv), ("ret", m.ret),
+                       ("old_logp", m.buf_logp), ("old_v", m.buf_val)):
+            torch.index_select(src, 1, idx, out=ug[k])
+        for dst, src in zip(ug["states"], m.rollout_states):
+            torch.index_select(src, 0, idx, out=dst)
+        ug["graph"].replay()
+        g_flat, g_st = m.flat.buf.clone(), ug["stats"].clone()
+        m.flat.zero()
+        loss, st = m._minibatch_loss(ug["obs"], ug["act"], ug["starts"], ug["adv"], ug["ret"], ug["old_logp"], ug["old_v"], ug["states"])
+        loss.backward()
+        e_flat = m.flat.buf.clone()
+        assert torch.allclose(g_st, st, rtol=1e-3, atol=1e-5), (trial, g_st.tolist(), st.tolist())
+        off = 0
+        for (n, p) in zip([n for n, _ in m.policy.named_parameters()], m.flat.params):
+            a, b = g_flat[off:off + p.numel()], e_flat[off:off + p.numel()]
+            off += p.numel()
+            err = float((a - b).norm() / (b.norm() + 1e-9))
+            assert err < 2e-2 and bool(torch.isfinite(a).all()), (trial, n, err)
