@@ -301,8 +301,32 @@ __global__ void zero_f32_kernel(float* __restrict__ p, int n)
     if (i < n) p[i] = 0.0f;
 }
 
-// out[c] += sum over a tile of rows of x[r][c]  (x row-major [M][N]); one block = ROWS_PER_BLOCK rows x all columns
-constexpr int COLSUM_ROWS = 256;
+// out[c] += sum over a tile of rows of x[r][c]  (x row-major [M][N]).  Wide rows (N % 8 == 0, N <= 2048): one lane owns 8
+// adjacent columns (one 16-byte load per row), the block's 256 lanes cover 256 / (N/8) rows per pass; narrow / odd N: one
+// lane per column.  Partial sums meet in out[] through fp32 atomics (out is cleared by zero_f32_kernel just before).
+constexpr int COLSUM_ROWS = 512;
+template <typename GT>
+__global__ void __launch_bounds__(256)
+colsum_vec_kernel(const GT* __restrict__ x, int64_t M, int N, float* __restrict__ out)
+{
+    const int groups = N / VEC;                              // column groups per row (<= 256)
+    const int rows_per_pass = 256 / groups;
+    const int g = threadIdx.x % groups, rl = threadIdx.x / groups;
+    if (rl >= rows_per_pass) return;
+    const int64_t r0 = int64_t(blockIdx.x) * COLSUM_ROWS;
+    const int64_t r1 = r0 + COLSUM_ROWS < M ? r0 + COLSUM_ROWS : M;
+    float acc[VEC], v[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+    for (int64_t r = r0 + rl; r < r1; r += rows_per_pass) {
+        Vec8<GT>::load(x + r * N + g * VEC, v);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] += v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) atomicAdd(out + g * VEC + k, acc[k]);
+}
+
 template <typename GT>
 __global__ void __launch_bounds__(256)
 colsum_kernel(const GT* __restrict__ x, int64_t M, int N, float* __restrict__ out)
@@ -499,7 +523,10 @@ int fdyn_colsum(const void* x, int bf16, int64_t M, int N, float* out, void* str
     hipLaunchKernelGGL(zero_f32_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, N);
     if (M > 0) {
         const unsigned nb = unsigned((M + COLSUM_ROWS - 1) / COLSUM_ROWS);
-        if (bf16) hipLaunchKernelGGL((colsum_kernel<uint16_t>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, M, N, out);
+        const bool wide = N % VEC == 0 && N / VEC <= 256 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+        if (bf16 && wide) hipLaunchKernelGGL((colsum_vec_kernel<uint16_t>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, M, N, out);
+        else if (bf16) hipLaunchKernelGGL((colsum_kernel<uint16_t>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, M, N, out);
+        else if (wide) hipLaunchKernelGGL((colsum_vec_kernel<float>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)x, M, N, out);
         else hipLaunchKernelGGL((colsum_kernel<float>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)x, M, N, out);
     }
     return int(hipGetLastError());

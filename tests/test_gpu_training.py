@@ -312,9 +312,10 @@ def test_fused_ppo_loss_and_colsum_match_torch():
         for a, b, name in zip(outs[0], outs[1], ("loss", "stats", "dmean", "dvalues", "dlog_std")):
             assert torch.allclose(a, b, rtol=2e-4, atol=2e-6 if name.startswith("d") else 2e-5), (name, clip_vf, float((a - b).abs().max()))
     for dt in (torch.float32, torch.bfloat16):
-        x = torch.randn(70001, 384, device="cuda").to(dt)
-        got, want = fused.colsum(x), x.double().sum(0)
-        assert float((got.double() - want).abs().max()) < 2e-2
+        for n in (384, 1024, 18, 4, 1):                      # 16-byte-vector path and the one-lane-per-column path
+            x = torch.randn(70001, n, device="cuda").to(dt)
+            got, want = fused.colsum(x), x.double().sum(0)
+            assert float((got.double() - want).abs().max()) < 2e-2, (dt, n)
 
 
 def test_update_graph_replays_match_eager_at_training_size():
