@@ -301,50 +301,98 @@ __global__ void zero_f32_kernel(float* __restrict__ p, int n)
     if (i < n) p[i] = 0.0f;
 }
 
-// out[c] += sum over a tile of rows of x[r][c]  (x row-major [M][N]).  Wide rows (N % 8 == 0, N <= 2048): one lane owns 8
-// adjacent columns (one 16-byte load per row), the block's 256 lanes cover 256 / (N/8) rows per pass; narrow / odd N: one
-// lane per column.  Partial sums meet in out[] through fp32 atomics (out is cleared by zero_f32_kernel just before).
-constexpr int COLSUM_ROWS = 512;
+// Column sums of x [M][N] in two stages without atomics (deterministic): stage 1 -- block b reduces its contiguous chunk of
+// rows to partial[b][0..N); stage 2 -- one lane per column adds the partials.  Wide rows (N % 8 == 0, N <= 2048): a lane
+// owns 8 adjacent columns (16-byte loads, four in flight), the block's 256 lanes cover 256 / (N/8) rows per pass and meet
+// in LDS.  Narrow rows (N in {1, 2, 4, 8}): the chunk is read as a flat stream, lane t always sees column t % N.
+constexpr int COLSUM_BLOCKS = 1024;
 template <typename GT>
 __global__ void __launch_bounds__(256)
-colsum_vec_kernel(const GT* __restrict__ x, int64_t M, int N, float* __restrict__ out)
+colsum_wide_kernel(const GT* __restrict__ x, int64_t M, int N, int64_t chunk, float* __restrict__ partial)
 {
+    __shared__ float s[256 * VEC];
     const int groups = N / VEC;                              // column groups per row (<= 256)
     const int rows_per_pass = 256 / groups;
     const int g = threadIdx.x % groups, rl = threadIdx.x / groups;
-    if (rl >= rows_per_pass) return;
-    const int64_t r0 = int64_t(blockIdx.x) * COLSUM_ROWS;
-    const int64_t r1 = r0 + COLSUM_ROWS < M ? r0 + COLSUM_ROWS : M;
-    float acc[VEC], v[VEC];
+    const int64_t r0 = int64_t(blockIdx.x) * chunk;
+    const int64_t r1 = r0 + chunk < M ? r0 + chunk : M;
+    float acc[VEC], v0[VEC], v1[VEC], v2[VEC], v3[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
-    for (int64_t r = r0 + rl; r < r1; r += rows_per_pass) {
-        Vec8<GT>::load(x + r * N + g * VEC, v);
+    if (rl < rows_per_pass) {
+        int64_t r = r0 + rl;
+        const int64_t step = rows_per_pass;
+        for (; r + 3 * step < r1; r += 4 * step) {
+            Vec8<GT>::load(x + r * N + g * VEC, v0);
+            Vec8<GT>::load(x + (r + step) * N + g * VEC, v1);
+            Vec8<GT>::load(x + (r + 2 * step) * N + g * VEC, v2);
+            Vec8<GT>::load(x + (r + 3 * step) * N + g * VEC, v3);
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] += v[k];
+            for (int k = 0; k < VEC; ++k) acc[k] += (v0[k] + v1[k]) + (v2[k] + v3[k]);
+        }
+        for (; r < r1; r += step) {
+            Vec8<GT>::load(x + r * N + g * VEC, v0);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] += v0[k];
+        }
     }
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) atomicAdd(out + g * VEC + k, acc[k]);
+    for (int k = 0; k < VEC; ++k) s[(rl * groups + g) * VEC + k] = acc[k];     // [rl][column]
+    __syncthreads();
+    for (int c = threadIdx.x; c < N; c += 256) {
+        float t = 0.0f;
+        for (int q = 0; q < rows_per_pass; ++q) t += s[q * N + c];
+        partial[int64_t(blockIdx.x) * N + c] = t;
+    }
 }
 
 template <typename GT>
 __global__ void __launch_bounds__(256)
-colsum_kernel(const GT* __restrict__ x, int64_t M, int N, float* __restrict__ out)
+colsum_narrow_kernel(const GT* __restrict__ x, int64_t M, int N /*1, 2, 4 or 8*/, int64_t chunk, float* __restrict__ partial)
 {
-    const int64_t r0 = int64_t(blockIdx.x) * COLSUM_ROWS;
-    const int64_t r1 = r0 + COLSUM_ROWS < M ? r0 + COLSUM_ROWS : M;
-    for (int c = threadIdx.x; c < N; c += blockDim.x) {
-        float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
-        int64_t r = r0;
-        for (; r + 3 < r1; r += 4) {                        // four independent loads in flight per lane
-            acc0 += Vec8<GT>::scalar(x[r * N + c]);
-            acc1 += Vec8<GT>::scalar(x[(r + 1) * N + c]);
-            acc2 += Vec8<GT>::scalar(x[(r + 2) * N + c]);
-            acc3 += Vec8<GT>::scalar(x[(r + 3) * N + c]);
-        }
-        for (; r < r1; ++r) acc0 += Vec8<GT>::scalar(x[r * N + c]);
-        atomicAdd(out + c, (acc0 + acc1) + (acc2 + acc3));
+    __shared__ float s[256];
+    const int64_t e0 = int64_t(blockIdx.x) * chunk * N;
+    const int64_t e1 = (int64_t(blockIdx.x) * chunk + chunk < M ? int64_t(blockIdx.x) * chunk + chunk : M) * N;
+    float a0 = 0.0f, a1 = 0.0f;
+    int64_t e = e0 + threadIdx.x;
+    for (; e + 256 < e1; e += 512) { a0 += Vec8<GT>::scalar(x[e]); a1 += Vec8<GT>::scalar(x[e + 256]); }
+    if (e < e1) a0 += Vec8<GT>::scalar(x[e]);
+    s[threadIdx.x] = a0 + a1;                                // e0 is a multiple of N and 256 % N == 0: lane t holds column t % N
+    __syncthreads();
+    if (threadIdx.x < N) {
+        float t = 0.0f;
+        for (int q = threadIdx.x; q < 256; q += N) t += s[q];
+        partial[int64_t(blockIdx.x) * N + threadIdx.x] = t;
     }
+}
+
+// any other N: one lane per column, rows of the chunk in sequence (correct, not fast)
+template <typename GT>
+__global__ void __launch_bounds__(256)
+colsum_generic_kernel(const GT* __restrict__ x, int64_t M, int N, int64_t chunk, float* __restrict__ partial)
+{
+    const int64_t r0 = int64_t(blockIdx.x) * chunk;
+    const int64_t r1 = r0 + chunk < M ? r0 + chunk : M;
+    for (int c = threadIdx.x; c < N; c += 256) {
+        float t = 0.0f;
+        for (int64_t r = r0; r < r1; ++r) t += Vec8<GT>::scalar(x[r * N + c]);
+        partial[int64_t(blockIdx.x) * N + c] = t;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+colsum_final_kernel(const float* __restrict__ partial, int nb, int N, float* __restrict__ out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int b = 0;
+    for (; b + 3 < nb; b += 4) {
+        a0 += partial[int64_t(b) * N + c]; a1 += partial[int64_t(b + 1) * N + c];
+        a2 += partial[int64_t(b + 2) * N + c]; a3 += partial[int64_t(b + 3) * N + c];
+    }
+    for (; b < nb; ++b) a0 += partial[int64_t(b) * N + c];
+    out[c] = (a0 + a1) + (a2 + a3);
 }
 
 // ws[0] += sum adv, ws[1] += sum adv^2
@@ -443,6 +491,24 @@ ppo_loss_kernel(const float* __restrict__ mean /*[M][4]*/, const float* __restri
 
 inline unsigned blocks(int64_t n) { return unsigned((n + 255) / 256); }
 
+template <typename GT>
+static void launch_colsum(const GT* x, int64_t M, int N, float* out, float* ws, hipStream_t st)
+{
+    int nb = int((M + 255) / 256);                           // at least 256 rows per block
+    nb = nb < 1 ? 1 : (nb > COLSUM_BLOCKS ? COLSUM_BLOCKS : nb);
+    const int64_t chunk = (M + nb - 1) / nb;
+    nb = int((M + chunk - 1) / chunk);
+    const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    if (N % VEC == 0 && N / VEC <= 256 && aligned)
+        hipLaunchKernelGGL((colsum_wide_kernel<GT>), dim3(nb), dim3(256), 0, st, x, M, N, chunk, ws);
+    else if (N == 1 || N == 2 || N == 4 || N == 8)
+        hipLaunchKernelGGL((colsum_narrow_kernel<GT>), dim3(nb), dim3(256), 0, st, x, M, N, chunk, ws);
+    else
+        hipLaunchKernelGGL((colsum_generic_kernel<GT>), dim3(nb), dim3(256), 0, st, x, M, N, chunk, ws);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, ws, nb, N, out);
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -516,18 +582,18 @@ int fdyn_lstm_seq_bwd(const void* act, int bf16, const float* c_prev, const floa
     return int(hipGetLastError());
 }
 
-int fdyn_colsum(const void* x, int bf16, int64_t M, int N, float* out, void* stream)
+int fdyn_colsum_ws_floats(int N) { return COLSUM_BLOCKS * N; }
+
+int fdyn_colsum(const void* x, int bf16, int64_t M, int N, float* out, float* ws, void* stream)
 {
     if (M < 0 || N <= 0) return FDYN_ERR_BAD_SIZE;
-    if (!out || (M > 0 && !x)) return FDYN_ERR_NULL;
-    hipLaunchKernelGGL(zero_f32_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, N);
-    if (M > 0) {
-        const unsigned nb = unsigned((M + COLSUM_ROWS - 1) / COLSUM_ROWS);
-        const bool wide = N % VEC == 0 && N / VEC <= 256 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-        if (bf16 && wide) hipLaunchKernelGGL((colsum_vec_kernel<uint16_t>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, M, N, out);
-        else if (bf16) hipLaunchKernelGGL((colsum_kernel<uint16_t>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, M, N, out);
-        else if (wide) hipLaunchKernelGGL((colsum_vec_kernel<float>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)x, M, N, out);
-        else hipLaunchKernelGGL((colsum_kernel<float>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)x, M, N, out);
+    if (!out || !ws || (M > 0 && !x)) return FDYN_ERR_NULL;
+    if (M == 0) {
+        hipLaunchKernelGGL(zero_f32_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, N);
+    } else if (bf16) {
+        launch_colsum<uint16_t>((const uint16_t*)x, M, N, out, ws, (hipStream_t)stream);
+    } else {
+        launch_colsum<float>((const float*)x, M, N, out, ws, (hipStream_t)stream);
     }
     return int(hipGetLastError());
 }

@@ -78,9 +78,11 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
         return x.sum(0, dtype=torch.float32)
     x = x.contiguous()
     M, N = x.shape
+    lib = _lib.load()
     out = torch.empty(N, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().fdyn_colsum(x.data_ptr(), int(x.dtype == torch.bfloat16), M, N, out.data_ptr(), _lib.current_stream()),
-               "colsum")
+    ws = torch.empty(lib.fdyn_colsum_ws_floats(N), dtype=torch.float32, device=x.device)
+    _lib.check(lib.fdyn_colsum(x.data_ptr(), int(x.dtype == torch.bfloat16), M, N, out.data_ptr(), ws.data_ptr(),
+                               _lib.current_stream()), "colsum")
     return out
 
 
