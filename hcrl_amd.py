@@ -16,7 +16,8 @@ class _AliasFinder:
         if not name.startswith("hcrl_amd."):
             return None
         real = importlib.import_module(_REAL + name[len("hcrl_amd"):])
-        sys.modules[name] = real
+        # do NOT pre-register sys.modules[name] here: importlib's _find_spec would then take the registered module's own
+        # spec (real name, source loader) and execute the file a second time -- two copies of every class
         return importlib.util.spec_from_loader(name, loader=_Loader(real))
 
 

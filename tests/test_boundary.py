@@ -150,3 +150,15 @@ def test_lstm_mfma_weight_stream_stays_inside_w(kx, kh):
                     origin = (p * H + sl * nslice) * K + ch * kc
                     worst = max(worst, int((origin + loff).max()) + 8)
     assert worst <= 4 * H * K, (worst, 4 * H * K)
+
+
+def test_alias_imports_are_the_same_module_objects():
+    """`hcrl_amd.x` and the real package's `x` must be ONE module (one copy of every class / enum / library handle)."""
+    import importlib
+    import sys
+    from hcrl_amd.flight_types import ControlMode as A
+    real = "hybrid-classical-and-reinforcement-learning-aircraft-controllers_amd"
+    for sub in ("flight_types", "config", "layout", "samplers", "_lib"):
+        importlib.import_module(f"hcrl_amd.{sub}")
+        assert sys.modules[f"hcrl_amd.{sub}"] is importlib.import_module(f"{real}.{sub}"), sub
+    assert A is importlib.import_module(f"{real}.flight_types").ControlMode
