@@ -216,14 +216,22 @@ def extras(args):
     """Short secondary measurements (same GPU, same batch) reported beside the headline; each ~1-3 s."""
     import copy
     res = {}
-    for wl_name, steps, warm in (("physics", 400, 40), ("cascade", 100, 10), ("rollout", 60, 6), ("train", 2, 1)):
+    # "*_saturation": the same kernels at a batch that fills the chip many times over (SURVEY 8d: "report physics-only
+    # saturation throughput"): 4 Mi aircraft / 1 Mi envs per GPU -- what the hardware sustains once launch cost is amortised
+    for key, wl_name, steps, warm, batch in (("physics", "physics", 400, 40, None), ("cascade", "cascade", 100, 10, None),
+                                             ("rollout", "rollout", 60, 6, None), ("train", "train", 2, 1, None),
+                                             ("physics_saturation", "physics", 100, 10, 1 << 22),
+                                             ("env_saturation", "env", 60, 6, 1 << 20)):
         try:
             a = copy.copy(args)
             a.workload, a.steps, a.warmup = wl_name, steps, warm
+            if batch is not None:
+                a.batch = batch
             wl = Workload(a, 0)
             wall, dev_ms, mode = timed_region(wl, a, 1)
+            wl_name = key
             res[wl_name] = {"value": wl.units_per_step * steps / wall, "ms_per_step": wall * 1e3 / steps,
-                            "unit": "env-steps/s" if wl_name in ("rollout", "train") else "aircraft-steps/s",
+                            "unit": "env-steps/s" if wl_name in ("rollout", "train", "env_saturation") else "aircraft-steps/s",
                             "workload": wl.desc}
             del wl
             torch.cuda.empty_cache()
