@@ -306,7 +306,7 @@ class RecurrentPPO:
                 print(f"[ppo] iter {it} steps {self.num_timesteps * world} fps {fps:,.0f} "
                       f"rew/step {st['mean_reward_per_step']:.3f} pl {st['policy_loss']:.4f} vl {st['value_loss']:.3f} "
                       f"kl {st['approx_kl']:.4f} clip {st['clip_frac']:.3f} gnorm {st['grad_norm']:.2f} "
-                      f"std {float(self.policy.log_std.exp().mean()):.3f}", flush=True)
+                      f"std {float(self.policy.log_std.detach().exp().mean()):.3f}", flush=True)
         return self
 
     def save(self, path):

@@ -27,6 +27,16 @@
  *                          learned_controllers/utils/pid_demonstrations.py:47-77)
  *                                                            learned_controllers/envs/rate_env.py:212-300,342-460,
  *                                                            learned_controllers/envs/rewards.py:48-137,168-221
+ *   fdyn_rate_metrics_*    MetricsCalculator.compute_metrics learned_controllers/eval/metrics.py:95-362 (fed by eval_rate.py:70-233)
+ *   fdyn_sensor_update_*   NoisySensorInterface.update       interfaces/sensor.py:199-243
+ *   fdyn_sensor_observe    the same noise model on RateControlEnv observations (rate_env.py:374-408 layout)
+ * Policy side (the reference delegates these to torch.nn.LSTM / SB3's PPO, which are not in its tree):
+ *   fdyn_lstm_cell_mfma, fdyn_policy_heads, fdyn_gaussian_head   rollout: LSTM cell / output heads of
+ *                          learned_controllers/networks/lstm_policy.py:13-136 (+ sb3_contrib's actor / critic LSTMs)
+ *   fdyn_lstm_cell_fwd/_bwd, fdyn_lstm_seq_fwd/_bwd              BPTT point-wise cell update and its gradient
+ *   fdyn_gae, fdyn_ppo_loss, fdyn_colsum                         GAE(lambda), clipped-surrogate loss + gradient, bias gradients
+ *                          (SB3 PPO.train semantics driven by learned_controllers/train_rate.py:128-147; parity unpinned --
+ *                          SB3 is absent -- and checked against the same arithmetic in plain torch)
  * The reference-side binding a maintainer would add (ctypes) is shown in INTEGRATION.md.
  */
 #ifndef FDYN_H
