@@ -491,13 +491,43 @@ ppo_loss_kernel(const float* __restrict__ mean /*[M][4]*/, const float* __restri
 
 inline unsigned blocks(int64_t n) { return unsigned((n + 255) / 256); }
 
-template <typename GT>
-static void launch_colsum(const GT* x, int64_t M, int N, float* out, float* ws, hipStream_t st)
+// grouped variant: rows come in segments of group_rows, segment j belonging to group j % n_groups (the [T][G][B] row order
+// of a multi-cell LSTM sequence); every stage-1 block lies inside one segment.  out [n_groups][N].
+__global__ void __launch_bounds__(256)
+colsum_final_grouped_kernel(const float* __restrict__ partial, int nb, int N, int blocks_per_segment, int n_groups,
+                            float* __restrict__ out)
 {
-    int nb = int((M + 255) / 256);                           // at least 256 rows per block
-    nb = nb < 1 ? 1 : (nb > COLSUM_BLOCKS ? COLSUM_BLOCKS : nb);
-    const int64_t chunk = (M + nb - 1) / nb;
-    nb = int((M + chunk - 1) / chunk);
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = blockIdx.y;
+    if (c >= N) return;
+    float a0 = 0.0f, a1 = 0.0f;
+    const int stride = blocks_per_segment * n_groups;
+    for (int base = g * blocks_per_segment; base < nb; base += stride) {
+        int b = base;
+        const int e = base + blocks_per_segment < nb ? base + blocks_per_segment : nb;
+        for (; b + 1 < e; b += 2) { a0 += partial[int64_t(b) * N + c]; a1 += partial[int64_t(b + 1) * N + c]; }
+        if (b < e) a0 += partial[int64_t(b) * N + c];
+    }
+    out[int64_t(g) * N + c] = a0 + a1;
+}
+
+static int64_t colsum_chunk(int64_t M, int64_t group_rows, int n_groups)
+{
+    if (n_groups <= 1) {
+        int64_t nb = (M + 255) / 256;
+        nb = nb < 1 ? 1 : (nb > COLSUM_BLOCKS ? COLSUM_BLOCKS : nb);
+        return (M + nb - 1) / nb;
+    }
+    int64_t d = group_rows < 512 ? group_rows : 512;        // largest divisor of group_rows that is <= 512
+    while (group_rows % d) --d;
+    return d;
+}
+
+template <typename GT>
+static void launch_colsum(const GT* x, int64_t M, int N, int64_t group_rows, int n_groups, float* out, float* ws, hipStream_t st)
+{
+    const int64_t chunk = colsum_chunk(M, group_rows, n_groups);
+    const int nb = int((M + chunk - 1) / chunk);
     const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
     if (N % VEC == 0 && N / VEC <= 256 && aligned)
         hipLaunchKernelGGL((colsum_wide_kernel<GT>), dim3(nb), dim3(256), 0, st, x, M, N, chunk, ws);
@@ -505,7 +535,11 @@ static void launch_colsum(const GT* x, int64_t M, int N, float* out, float* ws, 
         hipLaunchKernelGGL((colsum_narrow_kernel<GT>), dim3(nb), dim3(256), 0, st, x, M, N, chunk, ws);
     else
         hipLaunchKernelGGL((colsum_generic_kernel<GT>), dim3(nb), dim3(256), 0, st, x, M, N, chunk, ws);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, ws, nb, N, out);
+    if (n_groups <= 1)
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, ws, nb, N, out);
+    else
+        hipLaunchKernelGGL(colsum_final_grouped_kernel, dim3((N + 255) / 256, n_groups), dim3(256), 0, st, ws, nb, N,
+                           int(group_rows / chunk), n_groups, out);
 }
 
 
@@ -582,18 +616,23 @@ int fdyn_lstm_seq_bwd(const void* act, int bf16, const float* c_prev, const floa
     return int(hipGetLastError());
 }
 
-int fdyn_colsum_ws_floats(int N) { return COLSUM_BLOCKS * N; }
-
-int fdyn_colsum(const void* x, int bf16, int64_t M, int N, float* out, float* ws, void* stream)
+int64_t fdyn_colsum_ws_floats(int64_t M, int N, int64_t group_rows, int n_groups)
 {
-    if (M < 0 || N <= 0) return FDYN_ERR_BAD_SIZE;
+    const int64_t chunk = colsum_chunk(M < 1 ? 1 : M, group_rows < 1 ? 1 : group_rows, n_groups);
+    return ((M + chunk - 1) / chunk + 1) * int64_t(N);
+}
+
+int fdyn_colsum(const void* x, int bf16, int64_t M, int N, int64_t group_rows, int n_groups, float* out, float* ws, void* stream)
+{
+    if (M < 0 || N <= 0 || n_groups < 1) return FDYN_ERR_BAD_SIZE;
+    if (n_groups > 1 && (group_rows < 1 || M % (group_rows * n_groups))) return FDYN_ERR_BAD_SIZE;
     if (!out || !ws || (M > 0 && !x)) return FDYN_ERR_NULL;
     if (M == 0) {
-        hipLaunchKernelGGL(zero_f32_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, N);
+        hipLaunchKernelGGL(zero_f32_kernel, dim3((N * n_groups + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, N * n_groups);
     } else if (bf16) {
-        launch_colsum<uint16_t>((const uint16_t*)x, M, N, out, ws, (hipStream_t)stream);
+        launch_colsum<uint16_t>((const uint16_t*)x, M, N, group_rows, n_groups, out, ws, (hipStream_t)stream);
     } else {
-        launch_colsum<float>((const float*)x, M, N, out, ws, (hipStream_t)stream);
+        launch_colsum<float>((const float*)x, M, N, group_rows, n_groups, out, ws, (hipStream_t)stream);
     }
     return int(hipGetLastError());
 }

@@ -71,18 +71,21 @@ def lstm_cell(gates: torch.Tensor, c_prev: Optional[torch.Tensor]) -> Tuple[torc
 _BMM_F32_OUT = None
 
 
-def colsum(x: torch.Tensor) -> torch.Tensor:
+def colsum(x: torch.Tensor, group_rows: int = 0, n_groups: int = 1) -> torch.Tensor:
     """x [M, N] (bf16 / fp32, contiguous) -> fp32 [N] column sums (bias gradients): hand-written HIP reduction on the GPU
-    (graph-replay safe, unlike the generic multi-block reductions on this stack), plain torch on the CPU."""
-    if not x.is_cuda:
-        return x.sum(0, dtype=torch.float32)
-    x = x.contiguous()
+    (graph-replay safe, unlike the generic multi-block reductions on this stack), plain torch on the CPU.
+    n_groups > 1: rows come in segments of `group_rows`, segment j belonging to group j % n_groups -> [n_groups, N]."""
     M, N = x.shape
+    if not x.is_cuda:
+        if n_groups <= 1:
+            return x.sum(0, dtype=torch.float32)
+        return x.view(-1, n_groups, group_rows, N).sum((0, 2), dtype=torch.float32)
+    x = x.contiguous()
     lib = _lib.load()
-    out = torch.empty(N, dtype=torch.float32, device=x.device)
-    ws = torch.empty(lib.fdyn_colsum_ws_floats(N), dtype=torch.float32, device=x.device)
-    _lib.check(lib.fdyn_colsum(x.data_ptr(), int(x.dtype == torch.bfloat16), M, N, out.data_ptr(), ws.data_ptr(),
-                               _lib.current_stream()), "colsum")
+    out = torch.empty((n_groups, N) if n_groups > 1 else (N,), dtype=torch.float32, device=x.device)
+    ws = torch.empty(int(lib.fdyn_colsum_ws_floats(M, N, group_rows, n_groups)), dtype=torch.float32, device=x.device)
+    _lib.check(lib.fdyn_colsum(x.data_ptr(), int(x.dtype == torch.bfloat16), M, N, group_rows, n_groups, out.data_ptr(),
+                               ws.data_ptr(), _lib.current_stream()), "colsum")
     return out
 
 
@@ -93,9 +96,21 @@ def _sum_parts(part: torch.Tensor) -> torch.Tensor:
     return torch.mm(ones, part.view(S, N * K)).view(N, K)
 
 
+def _bmm_f32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """Batched GEMM with fp32 results straight from the MFMA accumulators where the build supports it."""
+    global _BMM_F32_OUT
+    if a.dtype != torch.float32 and _BMM_F32_OUT is not False:
+        try:
+            out = torch.bmm(a, b, out_dtype=torch.float32)
+            _BMM_F32_OUT = True
+            return out
+        except (TypeError, RuntimeError):
+            _BMM_F32_OUT = False
+    return torch.bmm(a, b).float()
+
+
 def wgrad_splitk(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     """dy [M, N], x [M, K] (same dtype) -> dy^T x as fp32 [N, K]."""
-    global _BMM_F32_OUT
     M, N = dy.shape
     K = x.shape[1]
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
@@ -104,15 +119,7 @@ def wgrad_splitk(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
         S *= 2
     if S == 1:
         return (dy.t() @ x).float()
-    a, b = dy.view(S, M // S, N).transpose(1, 2), x.view(S, M // S, K)
-    if dy.dtype != torch.float32 and _BMM_F32_OUT is not False:
-        try:                                              # fp32 partials straight from the MFMA accumulators
-            part = torch.bmm(a, b, out_dtype=torch.float32)
-            _BMM_F32_OUT = True
-            return _sum_parts(part)
-        except (TypeError, RuntimeError):
-            _BMM_F32_OUT = False
-    return _sum_parts(torch.bmm(a, b).float())
+    return _sum_parts(_bmm_f32(dy.view(S, M // S, N).transpose(1, 2), x.view(S, M // S, K)))
 
 
 class _SplitKLinearFn(torch.autograd.Function):
@@ -201,77 +208,102 @@ def deferred_linear(x: torch.Tensor, h: torch.Tensor, w: torch.Tensor, b: torch.
 
 
 class _LSTMSequenceFn(torch.autograd.Function):
-    """A recurrent LSTM layer over T steps as ONE autograd node (BPTT inside).  Per step and direction: one GEMM and one
-    fused point-wise launch (fdyn_lstm_seq_fwd / _bwd: masks, recurrent add, next-input packing folded in); the weight and
-    bias gradients are one split-K GEMM / one reduction over all T*B rows at the end of the backward loop."""
+    """G recurrent LSTM cells that read the same input sequence (the policy's actor and critic cells), over T steps, as ONE
+    autograd node (BPTT inside).  The cells ride a leading group dimension: per step and direction ONE batched GEMM and ONE
+    fused point-wise launch over G*B rows (fdyn_lstm_seq_fwd / _bwd: masks, recurrent add, next-input packing folded in);
+    the weight gradients are one batched split-K GEMM over all (t, g) blocks, the bias gradients one grouped column sum."""
 
     @staticmethod
-    def forward(ctx, feats, w_ih, w_hh, b_ih, b_hh, h0, c0, keep):
+    def forward(ctx, feats, keep, h0, c0, *params):
         lib = _lib.load()
+        G = len(params) // 4
         T, B, kx = feats.shape
-        H = w_hh.shape[1]
+        H = params[1].shape[1]
         K, dt, dev = kx + H, feats.dtype, feats.device
         bf16 = dt == torch.bfloat16
         assert bf16 or dt == torch.float32
-        assert w_ih.shape == (4 * H, kx) and w_hh.shape == (4 * H, H) and h0.shape == (B, H) and c0.shape == (B, H) and keep.shape == (T, B)
-        w = torch.cat([w_ih, w_hh], 1).to(dt)
-        b = (b_ih + b_hh).to(dt)
+        assert h0.shape == (G, B, H) and c0.shape == (G, B, H) and keep.shape == (T, B)
+        for g in range(G):
+            assert params[4 * g].shape == (4 * H, kx) and params[4 * g + 1].shape == (4 * H, H)
+        w = torch.stack([torch.cat([params[4 * g], params[4 * g + 1]], 1) for g in range(G)]).to(dt)          # [G, 4H, K]
+        b = torch.stack([params[4 * g + 2] + params[4 * g + 3] for g in range(G)]).to(dt).unsqueeze(1)       # [G, 1, 4H]
+        wT = w.transpose(1, 2)
         keep = keep.float().contiguous()
-        need = any(ctx.needs_input_grad[:5])
-        x_all = torch.empty((T, B, K), dtype=dt, device=dev)
-        x_all[:, :, :kx].copy_(feats)
-        x_all[0, :, kx:].copy_(h0.to(dt) * keep[0].unsqueeze(-1).to(dt))
-        act = torch.empty((T, B, 4 * H), dtype=dt, device=dev) if need else None
-        c_all = torch.empty((T + 1, B, H), dtype=torch.float32, device=dev)
+        keep_rows = keep.repeat(1, G).contiguous()                           # [T, G*B]: row g*B + b -> keep[t, b]
+        need = ctx.needs_input_grad[0] or any(ctx.needs_input_grad[4:])
+        x_all = torch.empty((T, G, B, K), dtype=dt, device=dev)
+        x_all[..., :kx].copy_(feats.unsqueeze(1))
+        x_all[0, :, :, kx:].copy_(h0.to(dt) * keep[0].view(1, B, 1).to(dt))
+        act = torch.empty((T, G, B, 4 * H), dtype=dt, device=dev) if need else None
+        c_all = torch.empty((T + 1, G, B, H), dtype=torch.float32, device=dev)
         c_all[0].copy_(c0)
-        h_seq = torch.empty((T, B, H), dtype=dt, device=dev)
-        st = _lib.current_stream()
+        h_seq = torch.empty((T, G, B, H), dtype=dt, device=dev)
+        st, R, esz = _lib.current_stream(), G * B, x_all.element_size()
         for t in range(T):
-            gates = torch.nn.functional.linear(x_all[t], w, b)
+            gates = torch.baddbmm(b, x_all[t], wT)                           # [G, B, 4H]
             last = t == T - 1
-            _lib.check(lib.fdyn_lstm_seq_fwd(gates.data_ptr(), int(bf16), c_all[t].data_ptr(), keep[t].data_ptr(), h_seq[t].data_ptr(),
-                                             c_all[t + 1].data_ptr(), act[t].data_ptr() if need else None,
-                                             None if last else x_all[t + 1].data_ptr() + kx * x_all.element_size(), K,
-                                             None if last else keep[t + 1].data_ptr(), B, H, st), "lstm_seq_fwd")
+            _lib.check(lib.fdyn_lstm_seq_fwd(gates.data_ptr(), int(bf16), c_all[t].data_ptr(), keep_rows[t].data_ptr(),
+                                             h_seq[t].data_ptr(), c_all[t + 1].data_ptr(), act[t].data_ptr() if need else None,
+                                             None if last else x_all[t + 1].data_ptr() + kx * esz, K,
+                                             None if last else keep_rows[t + 1].data_ptr(), R, H, st), "lstm_seq_fwd")
         if need:
-            ctx.save_for_backward(x_all, act, c_all, keep, w)
-            ctx.kx, ctx.param_dtypes = kx, (w_ih.dtype, w_hh.dtype, b_ih.dtype, b_hh.dtype)
+            ctx.save_for_backward(x_all, act, c_all, keep_rows, w)
+            ctx.kx, ctx.G, ctx.param_dtypes = kx, G, tuple(p.dtype for p in params)
         ctx.mark_non_differentiable(c_all)
         return h_seq, c_all
 
     @staticmethod
     def backward(ctx, dh_seq, _dc_all):
         lib = _lib.load()
-        x_all, act, c_all, keep, w = ctx.saved_tensors
-        T, B, K = x_all.shape
+        x_all, act, c_all, keep_rows, w = ctx.saved_tensors
+        T, G, B, K = x_all.shape
         H, kx, dt, dev = c_all.shape[-1], ctx.kx, x_all.dtype, x_all.device
         bf16 = dt == torch.bfloat16
         dh_seq = dh_seq.to(dt).contiguous()
-        dcat = torch.empty((T, B, K), dtype=dt, device=dev)
-        dc = [torch.empty((B, H), dtype=torch.float32, device=dev) for _ in range(2)]
-        st = _lib.current_stream()
+        dcat = torch.empty((T, G, B, K), dtype=dt, device=dev)
+        dc = [torch.empty((G, B, H), dtype=torch.float32, device=dev) for _ in range(2)]
+        st, R, esz = _lib.current_stream(), G * B, x_all.element_size()
         for t in range(T - 1, -1, -1):
             last = t == T - 1
             # dgates overwrite the saved activations in place: act becomes dY for the weight gradient below
-            _lib.check(lib.fdyn_lstm_seq_bwd(act[t].data_ptr(), int(bf16), c_all[t].data_ptr(), keep[t].data_ptr(), c_all[t + 1].data_ptr(),
-                                             dh_seq[t].data_ptr(), None if last else dcat[t + 1].data_ptr() + kx * dcat.element_size(), K,
-                                             None if last else keep[t + 1].data_ptr(), None if last else dc[(t + 1) & 1].data_ptr(),
-                                             act[t].data_ptr(), dc[t & 1].data_ptr(), B, H, st), "lstm_seq_bwd")
-            torch.mm(act[t], w, out=dcat[t])
-        dy = act.view(T * B, 4 * H)
-        dw = wgrad_splitk(dy, x_all.view(T * B, K)) if any(ctx.needs_input_grad[1:3]) else None
-        db = colsum(dy) if any(ctx.needs_input_grad[3:5]) else None
-        d = ctx.param_dtypes
-        return (dcat[:, :, :kx] if ctx.needs_input_grad[0] else None,
-                dw[:, :kx].to(d[0]) if ctx.needs_input_grad[1] else None, dw[:, kx:].to(d[1]) if ctx.needs_input_grad[2] else None,
-                db.to(d[2]) if ctx.needs_input_grad[3] else None, db.to(d[3]) if ctx.needs_input_grad[4] else None,
-                None, None, None)
+            _lib.check(lib.fdyn_lstm_seq_bwd(act[t].data_ptr(), int(bf16), c_all[t].data_ptr(), keep_rows[t].data_ptr(),
+                                             c_all[t + 1].data_ptr(), dh_seq[t].data_ptr(),
+                                             None if last else dcat[t + 1].data_ptr() + kx * esz, K,
+                                             None if last else keep_rows[t + 1].data_ptr(),
+                                             None if last else dc[(t + 1) & 1].data_ptr(), act[t].data_ptr(),
+                                             dc[t & 1].data_ptr(), R, H, st), "lstm_seq_bwd")
+            torch.bmm(act[t], w, out=dcat[t])
+        needs = ctx.needs_input_grad
+        grads = [None] * (4 * G)
+        if any(needs[4:]):
+            # dW_g = sum over (t, b) of dY^T X: one batched GEMM over the T*G row blocks (fp32), then a [1, T] GEMM over t
+            part = _bmm_f32(act.view(T * G, B, 4 * H).transpose(1, 2), x_all.view(T * G, B, K))     # [T*G, 4H, K]
+            ones = torch.ones((1, T), dtype=part.dtype, device=dev)
+            dw = torch.mm(ones, part.view(T, G * 4 * H * K)).view(G, 4 * H, K)
+            db = colsum(act.view(T * G * B, 4 * H), B, G).view(G, 4 * H)
+            d = ctx.param_dtypes
+            for g in range(G):
+                if needs[4 + 4 * g]:
+                    grads[4 * g] = dw[g, :, :kx].to(d[4 * g])
+                if needs[5 + 4 * g]:
+                    grads[4 * g + 1] = dw[g, :, kx:].to(d[4 * g + 1])
+                if needs[6 + 4 * g]:
+                    grads[4 * g + 2] = db[g].to(d[4 * g + 2])
+                if needs[7 + 4 * g]:
+                    grads[4 * g + 3] = db[g].to(d[4 * g + 3])
+        dfeats = None
+        if needs[0]:
+            dfeats = dcat[:, 0, :, :kx] if G == 1 else dcat[..., :kx].float().sum(1).to(dt) if G > 2 else \
+                (dcat[:, 0, :, :kx] + dcat[:, 1, :, :kx])
+        return (dfeats, None, None, None, *grads)
 
 
-def lstm_sequence(feats, w_ih, w_hh, b_ih, b_hh, h0, c0, keep):
-    """feats [T,B,kx] (compute dtype), parameters of one nn.LSTM layer, h0/c0 [B,H] (state before step 0, constants),
-    keep [T,B] (0 where an episode starts at that step) -> h_seq [T,B,H] (compute dtype), c_all [T+1,B,H] fp32."""
-    return _LSTMSequenceFn.apply(feats.contiguous(), w_ih, w_hh, b_ih, b_hh, h0, c0, keep)
+def lstm_sequence(feats, cells, h0, c0, keep):
+    """feats [T,B,kx] (compute dtype); cells = [(w_ih, w_hh, b_ih, b_hh), ...] parameters of G nn.LSTM layers that all read
+    `feats`; h0 / c0 [G,B,H] (states before step 0, constants); keep [T,B] (0 where an episode starts at that step)
+    -> h_seq [T,G,B,H] (compute dtype), c_all [T+1,G,B,H] fp32."""
+    flat = [p for cell in cells for p in cell]
+    return _LSTMSequenceFn.apply(feats.contiguous(), keep, h0, c0, *flat)
 
 
 class _PPOLossFn(torch.autograd.Function):

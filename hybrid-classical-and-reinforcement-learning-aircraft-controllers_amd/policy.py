@@ -292,11 +292,13 @@ class RateLSTMPolicy(nn.Module):
             wc, bc = torch.cat([lc.weight_ih_l0, lc.weight_hh_l0], 1), lc.bias_ih_l0 + lc.bias_hh_l0
             pi_h, pi_c, vf_h, vf_c = states
             if self.sequence_bptt and feats.is_cuda:
-                # each recurrent cell over all T steps is ONE autograd node (fused.lstm_sequence): 2 launches per step
-                # and direction, weight gradients from one split-K GEMM over all T*B rows
+                # the actor and critic cells over all T steps are ONE autograd node (fused.lstm_sequence): per step and
+                # direction one batched GEMM + one point-wise launch for both cells, weight gradients from one batched GEMM
                 keep_all = 1.0 - episode_starts.float()
-                pi_seq, _ = lstm_sequence(feats, la.weight_ih_l0, la.weight_hh_l0, la.bias_ih_l0, la.bias_hh_l0, pi_h, pi_c, keep_all)
-                vf_seq, _ = lstm_sequence(feats, lc.weight_ih_l0, lc.weight_hh_l0, lc.bias_ih_l0, lc.bias_hh_l0, vf_h, vf_c, keep_all)
+                cells = [(l.weight_ih_l0, l.weight_hh_l0, l.bias_ih_l0, l.bias_hh_l0) for l in (la, lc)]
+                h_seq, _ = lstm_sequence(feats, cells, torch.stack([pi_h.to(feats.dtype), vf_h.to(feats.dtype)]),
+                                         torch.stack([pi_c, vf_c]), keep_all)
+                pi_seq, vf_seq = h_seq[:, 0], h_seq[:, 1]
                 mean = linear(_run_seq(self.pi_net, pi_seq), self.action_net.weight, self.action_net.bias).float()
                 values = linear(_run_seq(self.vf_net, vf_seq), self.value_net.weight, self.value_net.bias).float().squeeze(-1)
                 return values, mean

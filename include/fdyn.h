@@ -155,15 +155,16 @@ int fdyn_lstm_seq_bwd(const void* act, int bf16, const float* c_prev, const floa
                       float* dc_prev, int64_t B, int H, void* stream);
 /* Reductions of the PPO update, self-contained so that a hipGraph replay recomputes them (accumulators are cleared by a
  * kernel of the same launch sequence).  fdyn_colsum: out [N] fp32 = column sums of x [M][N] (bf16 or fp32), two stages
- * through ws [fdyn_colsum_ws_floats(N)], no atomics: bias gradients.
+ * through ws [fdyn_colsum_ws_floats(...)], no atomics: bias gradients.  n_groups > 1: rows come in segments of group_rows,
+ * segment j belonging to group j % n_groups (the [T][G][B] row order of a multi-cell LSTM sequence); out [n_groups][N].
  * fdyn_ppo_loss: the clipped-surrogate loss of one slice of M samples and its gradient w.r.t. the policy outputs
  * (SB3 PPO.train semantics, which learned_controllers/train_rate.py:128-147 drives): mean, actions [M][4], log_std [4],
  * values, old_logp, adv, ret [M] (old_values [M] only if clip_range_vf > 0) -> dmean [M][4], dvalues [M],
  * stats [FDYN_PPO_NSTATS] = {policy loss, value loss, approx KL, clip fraction, policy + vf_coef * value,
  * d/dlog_std[4] of the log-prob part}; ws [2] scratch.  The entropy term is added by the caller.                         */
 #define FDYN_PPO_NSTATS 9
-int fdyn_colsum_ws_floats(int N);                       /* size of ws (floats) for N columns */
-int fdyn_colsum(const void* x, int bf16, int64_t M, int N, float* out, float* ws, void* stream);
+int64_t fdyn_colsum_ws_floats(int64_t M, int N, int64_t group_rows, int n_groups);   /* size of ws (floats) */
+int fdyn_colsum(const void* x, int bf16, int64_t M, int N, int64_t group_rows, int n_groups, float* out, float* ws, void* stream);
 int fdyn_ppo_loss(const float* mean, const float* actions, const float* log_std, const float* values, const float* old_logp,
                   const float* adv, const float* ret, const float* old_values, int normalize_adv, float clip_range,
                   float clip_range_vf, float vf_coef, int64_t M, float* dmean, float* dvalues, float* stats, float* ws,

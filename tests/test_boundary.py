@@ -22,7 +22,7 @@ PKG = os.path.join(REPO, "hybrid-classical-and-reinforcement-learning-aircraft-c
 def _declared_symbols():
     src = open(os.path.join(REPO, "include", "fdyn.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = set(re.findall(r"\bint\s+(fdyn_\w+)\s*\(", src))
+    names = set(re.findall(r"\b(?:int|int64_t)\s+(fdyn_\w+)\s*\(", src))
     # the env entry points are declared through FDYN_DECLARE_ENV(SUFFIX, S)
     names = {n for n in names if "##" not in n}
     for suffix in re.findall(r"FDYN_DECLARE_ENV\((\w+),", src):

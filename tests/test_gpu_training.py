@@ -316,6 +316,11 @@ def test_fused_ppo_loss_and_colsum_match_torch():
             x = torch.randn(70001, n, device="cuda").to(dt)
             got, want = fused.colsum(x), x.double().sum(0)
             assert float((got.double() - want).abs().max()) < 2e-2, (dt, n)
+        for (t_, g_, b_, n) in ((7, 2, 2048, 1024), (5, 3, 768, 128), (4, 2, 100, 64)):      # [T][G][B] row order
+            x = torch.randn(t_ * g_ * b_, n, device="cuda").to(dt)
+            got = fused.colsum(x, b_, g_)
+            want = x.double().view(t_, g_, b_, n).sum((0, 2))
+            assert got.shape == (g_, n) and float((got.double() - want).abs().max()) < 2e-2, (dt, t_, g_, b_, n)
 
 
 def test_update_graph_replays_match_eager_at_training_size():
