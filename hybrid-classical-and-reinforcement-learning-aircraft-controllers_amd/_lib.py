@@ -34,7 +34,7 @@ SIGNATURES = {
     "fdyn_rate_env_step_f32": (_i, _ENV_STEP),
     "fdyn_lstm_cell_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i64, _i, _p]),
     "fdyn_lstm_cell_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i64, _i, _p]),
-    "fdyn_lstm_seq_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i, _p]),
+    "fdyn_lstm_seq_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _i, _p]),
     "fdyn_lstm_seq_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _i64, _i, _p]),
     "fdyn_colsum_ws_floats": (_i64, [_i64, _i, _i64, _i]),
     "fdyn_colsum": (_i, [_p, _i, _i64, _i, _i64, _i, _p, _p, _p]),

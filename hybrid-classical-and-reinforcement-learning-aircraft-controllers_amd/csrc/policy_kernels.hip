@@ -71,7 +71,9 @@ lstm_cell_fwd_kernel(const GT* __restrict__ gates, const float* __restrict__ c_p
                      GT* __restrict__ h_lp, float* __restrict__ c_out, GT* __restrict__ act_out, int64_t total_vec, int H,
                      const float* __restrict__ keep = nullptr /*[B]: c_prev *= keep (episode start)*/,
                      GT* __restrict__ h_next = nullptr /*row stride next_stride: h * keep_next, the next step's input*/,
-                     int64_t next_stride = 0, const float* __restrict__ keep_next = nullptr)
+                     int64_t next_stride = 0, const float* __restrict__ keep_next = nullptr,
+                     const GT* __restrict__ bias = nullptr /*[rows / group_rows][4H]: added to the gates (batched GEMM has no epilogue)*/,
+                     int64_t group_rows = 1)
 {
     const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (t >= total_vec) return;
@@ -84,6 +86,24 @@ lstm_cell_fwd_kernel(const GT* __restrict__ gates, const float* __restrict__ c_p
     Vec8<GT>::load(g0 + 2 * H, gg);
     Vec8<GT>::load(g0 + 3 * H, go);
     if (c_prev) { Vec8<GT>::load(g0 + H, gf); Vec8<float>::load(c_prev + row * H + j, cp); }
+    if (bias) {
+        const GT* b0 = bias + (row / group_rows) * 4 * H + j;
+        float bv[VEC];
+        Vec8<GT>::load(b0, bv);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) gi[k] += bv[k];
+        Vec8<GT>::load(b0 + 2 * H, bv);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) gg[k] += bv[k];
+        Vec8<GT>::load(b0 + 3 * H, bv);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) go[k] += bv[k];
+        if (c_prev) {
+            Vec8<GT>::load(b0 + H, bv);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) gf[k] += bv[k];
+        }
+    }
     if (c_prev && keep) {
         const float kp = keep[row];
 #pragma unroll
@@ -580,20 +600,21 @@ int fdyn_lstm_cell_bwd(const void* act, int bf16, const float* c_prev, const flo
 }
 
 int fdyn_lstm_seq_fwd(const void* gates, int gates_bf16, const float* c_prev, const float* keep, void* h_lp, float* c_out,
-                      void* act_out, void* h_next, int64_t next_stride, const float* keep_next, int64_t B, int H, void* stream)
+                      void* act_out, void* h_next, int64_t next_stride, const float* keep_next, const void* bias,
+                      int64_t group_rows, int64_t B, int H, void* stream)
 {
-    if (B < 0 || H <= 0 || H % VEC || (h_next && next_stride < H)) return FDYN_ERR_BAD_SIZE;
+    if (B < 0 || H <= 0 || H % VEC || (h_next && next_stride < H) || (bias && group_rows < 1)) return FDYN_ERR_BAD_SIZE;
     if (!gates || !c_prev || !h_lp || !c_out) return FDYN_ERR_NULL;
     if (B == 0) return FDYN_OK;
     const int64_t tv = B * (H / VEC);
     if (gates_bf16)
         hipLaunchKernelGGL((lstm_cell_fwd_kernel<uint16_t>), dim3(blocks(tv)), dim3(256), 0, (hipStream_t)stream,
                            (const uint16_t*)gates, c_prev, (float*)nullptr, (uint16_t*)h_lp, c_out, (uint16_t*)act_out, tv, H, keep,
-                           (uint16_t*)h_next, next_stride, keep_next);
+                           (uint16_t*)h_next, next_stride, keep_next, (const uint16_t*)bias, group_rows);
     else
         hipLaunchKernelGGL((lstm_cell_fwd_kernel<float>), dim3(blocks(tv)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)gates, c_prev, (float*)nullptr, (float*)h_lp, c_out, (float*)act_out, tv, H, keep,
-                           (float*)h_next, next_stride, keep_next);
+                           (float*)h_next, next_stride, keep_next, (const float*)bias, group_rows);
     return int(hipGetLastError());
 }
 

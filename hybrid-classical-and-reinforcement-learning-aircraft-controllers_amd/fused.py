@@ -226,7 +226,7 @@ class _LSTMSequenceFn(torch.autograd.Function):
         for g in range(G):
             assert params[4 * g].shape == (4 * H, kx) and params[4 * g + 1].shape == (4 * H, H)
         w = torch.stack([torch.cat([params[4 * g], params[4 * g + 1]], 1) for g in range(G)]).to(dt)          # [G, 4H, K]
-        b = torch.stack([params[4 * g + 2] + params[4 * g + 3] for g in range(G)]).to(dt).unsqueeze(1)       # [G, 1, 4H]
+        b = torch.stack([params[4 * g + 2] + params[4 * g + 3] for g in range(G)]).to(dt).contiguous()      # [G, 4H]
         wT = w.transpose(1, 2)
         keep = keep.float().contiguous()
         keep_rows = keep.repeat(1, G).contiguous()                           # [T, G*B]: row g*B + b -> keep[t, b]
@@ -240,12 +240,13 @@ class _LSTMSequenceFn(torch.autograd.Function):
         h_seq = torch.empty((T, G, B, H), dtype=dt, device=dev)
         st, R, esz = _lib.current_stream(), G * B, x_all.element_size()
         for t in range(T):
-            gates = torch.baddbmm(b, x_all[t], wT)                           # [G, B, 4H]
+            gates = torch.bmm(x_all[t], wT)                                  # [G, B, 4H]; the bias is added in the cell kernel
             last = t == T - 1
             _lib.check(lib.fdyn_lstm_seq_fwd(gates.data_ptr(), int(bf16), c_all[t].data_ptr(), keep_rows[t].data_ptr(),
                                              h_seq[t].data_ptr(), c_all[t + 1].data_ptr(), act[t].data_ptr() if need else None,
                                              None if last else x_all[t + 1].data_ptr() + kx * esz, K,
-                                             None if last else keep_rows[t + 1].data_ptr(), R, H, st), "lstm_seq_fwd")
+                                             None if last else keep_rows[t + 1].data_ptr(), b.data_ptr(), B, R, H, st),
+                       "lstm_seq_fwd")
         if need:
             ctx.save_for_backward(x_all, act, c_all, keep_rows, w)
             ctx.kx, ctx.G, ctx.param_dtypes = kx, G, tuple(p.dtype for p in params)

@@ -145,11 +145,14 @@ int fdyn_lstm_cell_bwd(const void* act, int bf16, const float* c_prev, const flo
 /* One step of an LSTM SEQUENCE (BPTT over T inside one autograd node): the same point-wise kernels with the episode-start
  * masks and the recurrent plumbing folded in, so a step costs two launches each way (the GEMM and this).
  * fwd: c_prev is multiplied by keep [B] (NULL = 1); besides h_lp [B][H] the kernel stores h * keep_next into h_next (row
- *      stride next_stride elements: the recurrent columns of the NEXT step's [x | h] input row), or h_next = NULL.
+ *      stride next_stride elements: the recurrent columns of the NEXT step's [x | h] input row), or h_next = NULL;
+ *      bias [B / group_rows][4H] (gates dtype) or NULL is added to the gates of rows in group row / group_rows (a batched
+ *      GEMM over several cells has no bias epilogue).
  * bwd: dh_total = dh + dh2_keep * dh2 (dh2 = the recurrent columns of step t+1's input gradient, row stride dh2_stride,
  *      or NULL), summed in fp32; dgates may alias act (in place); dc_prev comes out already multiplied by keep.        */
 int fdyn_lstm_seq_fwd(const void* gates, int gates_bf16, const float* c_prev, const float* keep, void* h_lp, float* c_out,
-                      void* act_out, void* h_next, int64_t next_stride, const float* keep_next, int64_t B, int H, void* stream);
+                      void* act_out, void* h_next, int64_t next_stride, const float* keep_next, const void* bias,
+                      int64_t group_rows, int64_t B, int H, void* stream);
 int fdyn_lstm_seq_bwd(const void* act, int bf16, const float* c_prev, const float* keep, const float* c_new, const void* dh,
                       const void* dh2, int64_t dh2_stride, const float* dh2_keep, const float* dc_next, void* dgates,
                       float* dc_prev, int64_t B, int H, void* stream);
