@@ -235,13 +235,16 @@ def test_deferred_splitk_weight_gradients_match_plain_autograd(dtype, tol):
             fused.linear.__defaults__ = orig
         return {n: p.grad.detach().float().clone() for n, p in pol.named_parameters() if p.grad is not None}   # zero-state W_hh: unused
 
-    plain, fast, seq = grads(False, 1 << 60), grads(True, 8192), grads(True, 8192, sequence=True)
-    assert set(plain) == set(fast) == set(seq)
+    plain, fast, seq = grads(False, 1 << 60), grads(True, 8192), grads(True, 8192, sequence=True)    # seq: both cells in one node
+    pol.group_cells_max_batch = 0
+    seq1 = grads(True, 8192, sequence=True)                   # one node per cell (the large-slice path)
+    pol.group_cells_max_batch = 8192
+    assert set(plain) == set(fast) == set(seq) == set(seq1)
     for n in plain:
-        for other in (fast, seq):                             # seq: the whole recurrence as one autograd node
+        for other in (fast, seq, seq1):                       # seq: the whole recurrence as one autograd node
             a, b = plain[n], other[n]
             err = float((a - b).norm() / (a.norm() + 1e-12))
-            assert err < tol, (n, err, other is seq)
+            assert err < tol, (n, err, other is seq, other is seq1)
     # flat-buffer gradients (FlatGrad: p.grad are views that autograd and the deferred flush must ADD into)
     from hcrl_amd.ppo import FlatGrad
     flat = FlatGrad(pol)
