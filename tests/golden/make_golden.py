@@ -759,9 +759,43 @@ def gen_sensor():
     save("sensor_noisy.npz", **out)
 
 
+def gen_telemetry():
+    """The reference's TelemetryLogger (visualization/logger.py:9-152) fed a short two-aircraft flight: the JSON document it
+    writes, kept as the fixture (data), plus the inputs."""
+    import json, tempfile
+    print("telemetry file format (reference TelemetryLogger)")
+    logger_mod = _load_by_path("_ref_logger", "visualization/logger.py")
+    inputs = {"aircraft": {}}
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "flight.json")
+        log = logger_mod.TelemetryLogger(path)
+        log.register_aircraft("alpha", {"mission": "square", "speed": 15.0})
+        for name, thr in (("alpha", 0.7), ("bravo", 0.5)):          # bravo is auto-registered by its first log call
+            sim = Simplified6DOF()
+            sim.reset()
+            surf = ControlSurfaces(elevator=0.02, aileron=0.1, rudder=-0.03, throttle=thr)
+            sim.set_controls(surf)
+            rows = []
+            for k in range(4):
+                for _ in range(5):
+                    sim.step(0.002)
+                st = sim.get_state()
+                log.log_state(name, st)
+                log.log_command(name, ControlCommand(mode=ControlMode.RATE, roll_rate=0.1, pitch_rate=0.0, yaw_rate=0.0, throttle=thr), st.time)
+                log.log_surfaces(name, surf, st.time)
+                rows.append(np.concatenate([[st.time], state_vec(sim), [st.airspeed, st.altitude]]).tolist())
+            inputs["aircraft"][name] = {"rows": rows, "surfaces": [surf.elevator, surf.aileron, surf.rudder, surf.throttle]}
+        log.close()
+        doc = json.load(open(path))
+    with open(os.path.join(OUT, "telemetry_reference.json"), "w") as f:
+        json.dump({"inputs": inputs, "document": doc}, f)
+    print("   wrote telemetry_reference.json")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["open", "stress", "pid", "agents", "cfg1", "cfg3", "samplers", "env", "eval", "sensor"]
+    which = sys.argv[1:] or ["open", "stress", "pid", "agents", "cfg1", "cfg3", "samplers", "env", "eval", "sensor", "telemetry"]
     for w in which:
         {"open": gen_open_loop, "stress": gen_stress, "pid": gen_pid, "agents": gen_agents, "cfg1": gen_cfg1,
-         "cfg3": gen_cfg3, "samplers": gen_samplers, "env": gen_env, "eval": gen_eval, "sensor": gen_sensor}[w]()
+         "cfg3": gen_cfg3, "samplers": gen_samplers, "env": gen_env, "eval": gen_eval, "sensor": gen_sensor,
+         "telemetry": gen_telemetry}[w]()
     print("done")

@@ -116,3 +116,31 @@ def test_gym_env_reproduces_survey_episode():
     assert abs(st.altitude - info["altitude"]) < 1e-9
     obs2, _ = env.reset()                                         # next episode continues the sampler streams
     assert rel_err(obs2, obs).max() > 1e-3
+
+
+@pytest.mark.gpu
+def test_fleet_recorder_writes_the_telemetry_format(tmp_path):
+    """FleetRecorder: device-side samples of a cascade fleet written in the TelemetryLogger JSON schema."""
+    import json
+    from hcrl_amd import config as cfgmod
+    from hcrl_amd.fleet import BatchedCascade
+    from hcrl_amd.flight_types import ControllerConfig
+    from hcrl_amd.telemetry import FleetRecorder
+    mc = cfgmod.load_mission_config("square_pattern.yaml")
+    fleet = BatchedCascade(64, cfgmod.square_mission(mc.pattern_size, mc.altitude, mc.speed), "mixed", ControllerConfig(),
+                           cfgmod.load_controller_config("cascaded_pid.yaml"), guidance_type=mc.guidance)
+    x0 = np.zeros((64, 12)); x0[:, 2], x0[:, 3] = -mc.altitude, mc.speed
+    fleet.reset(x0)
+    rec = FleetRecorder(fleet, capacity=8, every=2)
+    for _ in range(12):
+        fleet.run(0.01, 10)
+        rec.sample(fleet.surfaces)
+    path = rec.write(str(tmp_path / "fleet.json"), aircraft=[0, 63], metadata={"mission": "square"})
+    doc = json.load(open(path))
+    assert set(doc["data"]) == {"aircraft_0", "aircraft_63"} and doc["metadata"]["aircraft_63"]["index"] == 63
+    d = doc["data"]["aircraft_0"]
+    assert len(d["states"]) == len(d["times"]) == len(d["surfaces"]) == 6 and d["commands"][0]["mode"] == "WAYPOINT"
+    assert abs(d["times"][1] - d["times"][0] - 0.2) < 1e-9 and set(d["states"][0]) == {"time", "position", "velocity", "attitude",
+                                                                                      "angular_rate", "airspeed", "altitude"}
+    x = fleet.state_numpy()[0]
+    assert d["times"][-1] < fleet.time and abs(d["states"][-1]["altitude"] - 100.0) < 20.0 and np.isfinite(x).all()
