@@ -400,19 +400,27 @@ colsum_generic_kernel(const GT* __restrict__ x, int64_t M, int N, int64_t chunk,
     }
 }
 
+// stage 2: a block owns 32 adjacent columns; its 8 row-slices of 32 lanes split the partial rows and meet in LDS
 __global__ void __launch_bounds__(256)
 colsum_final_kernel(const float* __restrict__ partial, int nb, int N, float* __restrict__ out)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-    int b = 0;
-    for (; b + 3 < nb; b += 4) {
-        a0 += partial[int64_t(b) * N + c]; a1 += partial[int64_t(b + 1) * N + c];
-        a2 += partial[int64_t(b + 2) * N + c]; a3 += partial[int64_t(b + 3) * N + c];
+    __shared__ float s[8][33];
+    const int cx = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    float a0 = 0.0f, a1 = 0.0f;
+    if (c < N) {
+        int b = sl;
+        for (; b + 8 < nb; b += 16) { a0 += partial[int64_t(b) * N + c]; a1 += partial[int64_t(b + 8) * N + c]; }
+        if (b < nb) a0 += partial[int64_t(b) * N + c];
     }
-    for (; b < nb; ++b) a0 += partial[int64_t(b) * N + c];
-    out[c] = (a0 + a1) + (a2 + a3);
+    s[sl][cx] = a0 + a1;
+    __syncthreads();
+    if (sl == 0 && c < N) {
+        float t = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += s[q][cx];
+        out[c] = t;
+    }
 }
 
 // ws[0] += sum adv, ws[1] += sum adv^2
@@ -517,18 +525,26 @@ __global__ void __launch_bounds__(256)
 colsum_final_grouped_kernel(const float* __restrict__ partial, int nb, int N, int blocks_per_segment, int n_groups,
                             float* __restrict__ out)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float s[8][33];
+    const int cx = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
     const int g = blockIdx.y;
-    if (c >= N) return;
-    float a0 = 0.0f, a1 = 0.0f;
-    const int stride = blocks_per_segment * n_groups;
-    for (int base = g * blocks_per_segment; base < nb; base += stride) {
-        int b = base;
-        const int e = base + blocks_per_segment < nb ? base + blocks_per_segment : nb;
-        for (; b + 1 < e; b += 2) { a0 += partial[int64_t(b) * N + c]; a1 += partial[int64_t(b + 1) * N + c]; }
-        if (b < e) a0 += partial[int64_t(b) * N + c];
+    float a0 = 0.0f;
+    if (c < N) {
+        const int stride = blocks_per_segment * n_groups;
+        for (int base = g * blocks_per_segment; base < nb; base += stride) {
+            const int e = base + blocks_per_segment < nb ? base + blocks_per_segment : nb;
+            for (int b = base + sl; b < e; b += 8) a0 += partial[int64_t(b) * N + c];
+        }
     }
-    out[int64_t(g) * N + c] = a0 + a1;
+    s[sl][cx] = a0;
+    __syncthreads();
+    if (sl == 0 && c < N) {
+        float t = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += s[q][cx];
+        out[int64_t(g) * N + c] = t;
+    }
 }
 
 static int64_t colsum_chunk(int64_t M, int64_t group_rows, int n_groups)
@@ -556,9 +572,9 @@ static void launch_colsum(const GT* x, int64_t M, int N, int64_t group_rows, int
     else
         hipLaunchKernelGGL((colsum_generic_kernel<GT>), dim3(nb), dim3(256), 0, st, x, M, N, chunk, ws);
     if (n_groups <= 1)
-        hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, ws, nb, N, out);
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 31) / 32), dim3(256), 0, st, ws, nb, N, out);
     else
-        hipLaunchKernelGGL(colsum_final_grouped_kernel, dim3((N + 255) / 256, n_groups), dim3(256), 0, st, ws, nb, N,
+        hipLaunchKernelGGL(colsum_final_grouped_kernel, dim3((N + 31) / 32, n_groups), dim3(256), 0, st, ws, nb, N,
                            int(group_rows / chunk), n_groups, out);
 }
 
