@@ -14,7 +14,7 @@ import torch.distributed as dist
 
 from .policy import RateLSTMPolicy
 from .ppo import PPOConfig, RecurrentPPO
-from .training_utils import (behavior_cloning_pretrain, collect_pid_demonstrations, create_vec_env, load_config,
+from .training_utils import (behavior_cloning_pretrain, collect_pid_demonstrations, create_callbacks, create_vec_env, load_config,
                              run_final_evaluation)
 
 DEFAULT_CONFIG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs", "training", "ppo_lstm.yaml")
@@ -30,6 +30,9 @@ def main(argv=None):
     ap.add_argument("--set", action="append", default=[], metavar="SECTION.KEY=VALUE",
                     help="override a config entry, e.g. --set ppo.learning_rate=1e-3 --set training.n_envs=4096")
     ap.add_argument("--bf16", action="store_true", help="run the policy GEMMs in bf16 (fp32 accumulate)")
+    ap.add_argument("--resume", type=str, default=None, help="checkpoint (RecurrentPPO.save) to continue from")
+    ap.add_argument("--callbacks", action="store_true",
+                    help="periodic evaluation (best model, evaluations.npz) and checkpoints per the config's eval_freq / save_freq")
     args = ap.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -62,6 +65,12 @@ def main(argv=None):
     env = create_vec_env(config, n_envs=n_envs, seed=seed + rank * n_envs, precision=args.precision)
     model = RecurrentPPO(env, policy, PPOConfig.from_dict(config["ppo"]), seed=seed)
 
+    if args.resume:
+        model.load(args.resume)
+        if rank == 0:
+            print(f"resumed from {args.resume} at {model.num_timesteps} timesteps")
+    callback = create_callbacks(config) if (args.callbacks and rank == 0) else None
+
     if args.bc_pretrain and rank == 0:
         obs, acts = collect_pid_demonstrations(n_episodes=2048, difficulty="medium", seed=seed)
         print("BC losses:", behavior_cloning_pretrain(model, obs, acts, epochs=args.bc_pretrain))
@@ -77,10 +86,11 @@ def main(argv=None):
             model.set_env(env)
             if rank == 0:
                 print(f"=== phase {phase['name']}: {phase['difficulty']}/{phase['command_type']} {phase['timesteps']} steps")
-            model.learn(int(phase["timesteps"] * args.timesteps_scale), log_interval=config["training"]["log_interval"])
+            model.learn(int(phase["timesteps"] * args.timesteps_scale), log_interval=config["training"]["log_interval"],
+                        callback=callback)
     else:
         model.learn(int(config["training"]["total_timesteps"] * args.timesteps_scale),
-                    log_interval=config["training"]["log_interval"])
+                    log_interval=config["training"]["log_interval"], callback=callback)
 
     if rank == 0:
         os.makedirs(config["paths"]["model_save_dir"], exist_ok=True)

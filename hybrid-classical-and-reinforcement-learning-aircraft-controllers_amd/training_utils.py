@@ -101,3 +101,84 @@ def run_final_evaluation(model, difficulty="hard", n_episodes=10, dt=0.02, seed=
             break
     return {"mean_length": float(length.mean()), "mean_reward": float(ret.mean()), "lengths": length.cpu().numpy(),
             "rewards": ret.cpu().numpy()}
+
+
+# ---- callbacks: learned_controllers/utils/training_utils.py:72-156 (SB3's EvalCallback / CheckpointCallback there) -----------
+class CheckpointCallback:
+    """Saves `<save_path>/<name_prefix>_<num_timesteps>_steps.pt` every `save_freq` vec-env steps (SB3 counts callback calls,
+    one per vec-env step: num_timesteps / n_envs)."""
+
+    def __init__(self, save_freq: int, save_path: str, name_prefix: str = "rate_controller"):
+        self.save_freq, self.save_path, self.name_prefix = max(int(save_freq), 1), save_path, name_prefix
+        self._last = 0
+        self.saved = []
+
+    def __call__(self, model, stats):
+        n_calls = model.num_timesteps // model.env.num_envs
+        if n_calls // self.save_freq > self._last:
+            self._last = n_calls // self.save_freq
+            os.makedirs(self.save_path, exist_ok=True)
+            path = os.path.join(self.save_path, f"{self.name_prefix}_{model.num_timesteps}_steps.pt")
+            model.save(path)
+            self.saved.append(path)
+
+
+class EvalCallback:
+    """Every `eval_freq` vec-env steps: `n_eval_episodes` deterministic episodes on a fresh env, results appended to
+    `<log_path>/evaluations.npz` (arrays `timesteps`, `results`, `ep_lengths` -- the file recover_training.py:18-95 reads) and
+    the best mean reward so far kept as `<best_model_save_path>/best_model.pt`."""
+
+    def __init__(self, difficulty: str, best_model_save_path: str, log_path: str, eval_freq: int, n_eval_episodes: int = 10,
+                 deterministic: bool = True):
+        self.difficulty, self.best_dir, self.log_dir = difficulty, best_model_save_path, log_path
+        self.eval_freq, self.n_eval_episodes, self.deterministic = max(int(eval_freq), 1), n_eval_episodes, deterministic
+        self._last, self.best_mean_reward = 0, -float("inf")
+        self.timesteps, self.results, self.ep_lengths = [], [], []
+
+    def __call__(self, model, stats):
+        n_calls = model.num_timesteps // model.env.num_envs
+        if n_calls // self.eval_freq <= self._last:
+            return
+        self._last = n_calls // self.eval_freq
+        ev = run_final_evaluation(model, difficulty=self.difficulty, n_episodes=self.n_eval_episodes)
+        self.timesteps.append(model.num_timesteps); self.results.append(ev["rewards"]); self.ep_lengths.append(ev["lengths"])
+        os.makedirs(self.log_dir, exist_ok=True)
+        np.savez(os.path.join(self.log_dir, "evaluations.npz"), timesteps=np.array(self.timesteps),
+                 results=np.array(self.results), ep_lengths=np.array(self.ep_lengths))
+        if ev["mean_reward"] > self.best_mean_reward:
+            self.best_mean_reward = ev["mean_reward"]
+            os.makedirs(self.best_dir, exist_ok=True)
+            model.save(os.path.join(self.best_dir, "best_model.pt"))
+
+
+class CallbackList:
+    def __init__(self, callbacks):
+        self.callbacks = list(callbacks)
+
+    def __call__(self, model, stats):
+        for cb in self.callbacks:
+            cb(model, stats)
+
+
+def create_callbacks(config: dict, eval_env=None, flight_logger=None) -> CallbackList:
+    """training_utils.py:72-156: evaluation + checkpoint callbacks from the `paths` / `training` / `evaluation` sections.
+    (`eval_env` is accepted for signature compatibility; evaluation builds its own device env.  The reference's optional
+    TensorBoard flight-logging callback needs its tensorboard plugin, which is outside the hot path.)"""
+    paths, tr, ev = config["paths"], config["training"], config.get("evaluation", {})
+    difficulty = config.get("environment", {}).get("difficulty", "medium")
+    return CallbackList([
+        EvalCallback(difficulty, paths["best_model_path"], paths["best_model_path"], tr["eval_freq"],
+                     ev.get("n_eval_episodes", 10), ev.get("deterministic", True)),
+        CheckpointCallback(tr["save_freq"], paths["model_save_dir"], "rate_controller")])
+
+
+def find_best_checkpoint(log_path: str):
+    """recover_training.py:18-95: the evaluation with the highest mean reward in `<log_path>/evaluations.npz`
+    -> (timesteps, mean_reward) or None."""
+    f = os.path.join(log_path, "evaluations.npz")
+    if not os.path.exists(f):
+        return None
+    d = np.load(f)
+    means = d["results"].mean(axis=1)
+    i = int(np.argmax(means))
+    return int(d["timesteps"][i]), float(means[i])

@@ -1,4 +1,6 @@
 """GPU: the policy / PPO / BC glue on the real device-resident env."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -176,6 +178,34 @@ def test_train_rate_cli_end_to_end(tmp_path):
     train_rate.main(["--config", str(p), "--bf16", "--bc-pretrain", "1"])
     ck = torch.load(tmp_path / "ckpt" / "final_model.pt", weights_only=True)
     assert ck["num_timesteps"] == 3 * 512 * 8 and "policy" in ck
+
+
+def test_callbacks_checkpoints_best_model_and_resume(tmp_path):
+    """create_callbacks (training_utils.py:72-156): periodic checkpoints, evaluations.npz + best model, then --resume
+    continues the timestep count from a checkpoint."""
+    import yaml
+    from hcrl_amd import train_rate
+    from hcrl_amd.training_utils import find_best_checkpoint
+    cfg = yaml.safe_load(open(train_rate.DEFAULT_CONFIG))
+    cfg["training"].update(n_envs=256, total_timesteps=256 * 8 * 6, eval_freq=16, save_freq=24)      # in vec-env steps
+    cfg["curriculum"]["enabled"] = False
+    cfg["ppo"].update(n_steps=8, n_epochs=1)
+    cfg["evaluation"]["n_eval_episodes"] = 8
+    cfg["paths"] = {"model_save_dir": str(tmp_path / "ckpt"), "tensorboard_log": str(tmp_path / "tb"),
+                    "best_model_path": str(tmp_path / "best")}
+    p = tmp_path / "cfg.yaml"
+    p.write_text(yaml.safe_dump(cfg))
+    train_rate.main(["--config", str(p), "--callbacks"])
+    saved = sorted(f for f in os.listdir(tmp_path / "ckpt") if f.startswith("rate_controller_"))
+    assert saved == ["rate_controller_12288_steps.pt", "rate_controller_6144_steps.pt"], saved       # every 24 vec-steps
+    ev = np.load(tmp_path / "best" / "evaluations.npz")
+    assert list(ev["timesteps"]) == [4096, 8192, 12288] and ev["results"].shape == (3, 8) and ev["ep_lengths"].shape == (3, 8)
+    assert (tmp_path / "best" / "best_model.pt").exists()
+    best = find_best_checkpoint(str(tmp_path / "best"))
+    assert best[0] in (4096, 8192, 12288) and abs(best[1] - ev["results"].mean(1).max()) < 1e-6
+    train_rate.main(["--config", str(p), "--resume", str(tmp_path / "ckpt" / "rate_controller_6144_steps.pt")])
+    ck = torch.load(tmp_path / "ckpt" / "final_model.pt", weights_only=True)
+    assert ck["num_timesteps"] == 6144 + 256 * 8 * 6
 
 
 def test_gaussian_head_statistics_and_logprob():
