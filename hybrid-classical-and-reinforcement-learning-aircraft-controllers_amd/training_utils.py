@@ -151,6 +151,21 @@ class EvalCallback:
             model.save(os.path.join(self.best_dir, "best_model.pt"))
 
 
+class ProgressLogger:
+    """Per-iteration scalars as JSON lines in `<tensorboard_log>/progress.jsonl` (the reference hands `tensorboard_log` to SB3,
+    train_rate.py:144; TensorBoard is not in this image, the scalars are the same: losses, KL, clip fraction, reward)."""
+
+    def __init__(self, log_dir: str):
+        os.makedirs(log_dir, exist_ok=True)
+        self.path = os.path.join(log_dir, "progress.jsonl")
+        self._f = open(self.path, "a")
+
+    def __call__(self, model, stats):
+        import json
+        self._f.write(json.dumps({"timesteps": int(model.num_timesteps), **{k: float(v) for k, v in stats.items()}}) + "\n")
+        self._f.flush()
+
+
 class CallbackList:
     def __init__(self, callbacks):
         self.callbacks = list(callbacks)
@@ -169,7 +184,8 @@ def create_callbacks(config: dict, eval_env=None, flight_logger=None) -> Callbac
     return CallbackList([
         EvalCallback(difficulty, paths["best_model_path"], paths["best_model_path"], tr["eval_freq"],
                      ev.get("n_eval_episodes", 10), ev.get("deterministic", True)),
-        CheckpointCallback(tr["save_freq"], paths["model_save_dir"], "rate_controller")])
+        CheckpointCallback(tr["save_freq"], paths["model_save_dir"], "rate_controller"),
+        ProgressLogger(paths["tensorboard_log"])])
 
 
 def find_best_checkpoint(log_path: str):

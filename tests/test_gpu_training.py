@@ -201,6 +201,9 @@ def test_callbacks_checkpoints_best_model_and_resume(tmp_path):
     ev = np.load(tmp_path / "best" / "evaluations.npz")
     assert list(ev["timesteps"]) == [4096, 8192, 12288] and ev["results"].shape == (3, 8) and ev["ep_lengths"].shape == (3, 8)
     assert (tmp_path / "best" / "best_model.pt").exists()
+    import json
+    rows = [json.loads(l) for l in open(tmp_path / "tb" / "progress.jsonl")]
+    assert [r["timesteps"] for r in rows] == [2048 * k for k in range(1, 7)] and "approx_kl" in rows[0]
     best = find_best_checkpoint(str(tmp_path / "best"))
     assert best[0] in (4096, 8192, 12288) and abs(best[1] - ev["results"].mean(1).max()) < 1e-6
     train_rate.main(["--config", str(p), "--resume", str(tmp_path / "ckpt" / "rate_controller_6144_steps.pt")])
