@@ -202,6 +202,82 @@ cascade_step_kernel(S* __restrict__ xs, float* __restrict__ pid_state /*[9*3][n]
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// One cascade LEVEL commanded directly, per aircraft: n_steps x {agent.compute_action(command, state, dt) -> set_controls ->
+// one RK4 of dt}, or with n_steps == 0 just compute_action (no physics).  This is how the reference's tests and examples
+// drive RateAgent / AttitudeAgent / HSAAgent / WaypointAgent (controllers/*_agent.py; closed-loop helper
+// tests/test_control_integration.py:34-74).  cmd rows by level:
+//   FD_LEVEL_RATE     p, q, r [rad/s], throttle            FD_LEVEL_HSA       heading [rad], speed [m/s], altitude [m], -
+//   FD_LEVEL_ATTITUDE roll, pitch, yaw (NaN = none), thr   FD_LEVEL_WAYPOINT  north, east, altitude, speed (NaN = keep)
+// ---------------------------------------------------------------------------------------------------------
+template <typename S, typename T>
+__global__ void __launch_bounds__(FD_BLOCK)
+agent_step_kernel(int level, S* __restrict__ xs, float* __restrict__ pid_state /*[9*3][n]*/, const uint8_t* __restrict__ type,
+                  const double* __restrict__ params, int n_types, const float* __restrict__ pid_cfg,
+                  const double* __restrict__ consts, const S* __restrict__ cmd /*[4][n]*/, int64_t n, S dt, int n_steps,
+                  S* __restrict__ surf_out /*[4][n]*/, int lpw)
+{
+    __shared__ double s_params[FD_MAX_TYPES * FD_NP];
+    __shared__ float s_pid_cfg[FD_NPID * FD_NPC];
+    __shared__ S s_consts[FD_NC];
+    stage(s_params, params, n_types * FD_NP);
+    stage(s_pid_cfg, pid_cfg, FD_NPID * FD_NPC);
+    for (int k = threadIdx.x; k < FD_NC; k += blockDim.x) s_consts[k] = S(consts[k]);
+    __syncthreads();
+    const LaneMap lm = lane_map(lpw, n);
+    const int64_t i = lm.i;
+    if (!lm.on) return;
+    const double* blk = s_params + lane_type(type, i, n_types) * FD_NP;
+    Params<T> P; P.load(blk);
+    Limits<S> Lm; Lm.load(blk);
+    PidCfg cfg[FD_NPID];
+    PidState st[FD_NPID];
+#pragma unroll
+    for (int k = 0; k < FD_NPID; ++k) {
+        cfg[k] = load_pid_cfg(s_pid_cfg, k);
+        st[k] = PidState{ pid_state[(k * FD_NPS + FD_PS_INTEGRAL) * n + i], pid_state[(k * FD_NPS + FD_PS_ERR_PREV) * n + i],
+                          pid_state[(k * FD_NPS + FD_PS_DFILT) * n + i] };
+    }
+    S x[FD_NX];
+#pragma unroll
+    for (int k = 0; k < FD_NX; ++k) x[k] = xs[k * n + i];
+    const S c0 = cmd[i], c1 = cmd[n + i], c2 = cmd[2 * n + i], c3 = cmd[3 * n + i];
+    Surfaces<S> surf{ S(0), S(0), S(0), S(0) };
+    const int iters = n_steps > 0 ? n_steps : 1;
+    for (int s = 0; s < iters; ++s) {
+        if (level == FD_LEVEL_RATE) {
+            surf = rate_agent<S>(cfg, st, s_consts, c0, c1, c2, c3, x, dt);
+        } else if (level == FD_LEVEL_ATTITUDE) {
+            const bool has_yaw = c2 == c2;
+            surf = attitude_agent<S>(cfg, st, s_consts, c0, c1, has_yaw ? c2 : S(0), has_yaw, c3, x, dt);
+        } else if (level == FD_LEVEL_HSA) {
+            surf = hsa_agent<S>(cfg, st, s_consts, c0, c1, c2, x, derived<S>(x), dt);
+        } else {
+            const S wp[FD_NWP] = { c0, c1, c2, c3 };
+            surf = waypoint_agent<S>(cfg, st, s_consts, wp, x, derived<S>(x), dt);
+        }
+        if (n_steps > 0) {
+            Controls<T> C;
+            C.set(P, surf.elevator, surf.aileron, surf.rudder, surf.throttle);
+            rk4_substeps<S, T>(P, Lm, C, x, dt, 1);
+        }
+    }
+    if (n_steps > 0) {
+#pragma unroll
+        for (int k = 0; k < FD_NX; ++k) xs[k * n + i] = x[k];
+    }
+#pragma unroll
+    for (int k = 0; k < FD_NPID; ++k) {
+        pid_state[(k * FD_NPS + FD_PS_INTEGRAL) * n + i] = st[k].integral;
+        pid_state[(k * FD_NPS + FD_PS_ERR_PREV) * n + i] = st[k].err_prev;
+        pid_state[(k * FD_NPS + FD_PS_DFILT) * n + i] = st[k].dfilt;
+    }
+    if (surf_out) {
+        surf_out[FD_U_ELEVATOR * n + i] = surf.elevator; surf_out[FD_U_AILERON * n + i] = surf.aileron;
+        surf_out[FD_U_RUDDER * n + i] = surf.rudder; surf_out[FD_U_THROTTLE * n + i] = surf.throttle;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // K3+K4: RateControlEnv.step for a whole vec-env, with done compaction and in-kernel auto-reset
 // ---------------------------------------------------------------------------------------------------------
 template <typename G> struct EnvConsts {
@@ -723,6 +799,25 @@ int fdyn_pid_compute_batch(const float* cfg, int cfg_per_lane, float* state, con
                            n_steps, surf_out, reached_total, lpw);                                           \
         return launch_status();                                                                              \
     }
+#define FD_DEFINE_AGENT(NAME, S, T)                                                                          \
+    int NAME(int level, S* x, float* pid_state, const uint8_t* type, const double* params, int n_types,      \
+             const float* pid_cfg, const double* consts, const S* cmd, int64_t n, double dt, int n_steps,    \
+             S* surf_out, void* stream)                                                                      \
+    {                                                                                                        \
+        FD_CHECK_COMMON(n, n_types)                                                                          \
+        if (level < FD_LEVEL_WAYPOINT || level > FD_LEVEL_RATE || n_steps < 0) return FDYN_ERR_BAD_SIZE;     \
+        if (n > 0 && (!x || !pid_state || !pid_cfg || !consts || !cmd)) return FDYN_ERR_NULL;                \
+        if (!(dt > 1e-6) || dt > 1.0) return FDYN_ERR_BAD_DT;                                                \
+        const int lpw = pick_lpw(n);                                                                         \
+        hipLaunchKernelGGL((agent_step_kernel<S, T>), dim3(grid_lpw(n, lpw)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
+                           level, x, pid_state, type, params, n_types, pid_cfg, consts, cmd, n, S(dt), n_steps, \
+                           surf_out, lpw);                                                                   \
+        return launch_status();                                                                              \
+    }
+FD_DEFINE_AGENT(fdyn_agent_step_f64, double, double)
+FD_DEFINE_AGENT(fdyn_agent_step_mixed, double, float)
+FD_DEFINE_AGENT(fdyn_agent_step_f32, float, float)
+
 FD_DEFINE_CASCADE(fdyn_cascade_step_f64, double, double)
 FD_DEFINE_CASCADE(fdyn_cascade_step_mixed, double, float)
 FD_DEFINE_CASCADE(fdyn_cascade_step_f32, float, float)

@@ -22,6 +22,7 @@
  *                          + set_controls + step             examples/03_waypoint_square_demo.py:148-209,
  *                          controllers/{mission_planner.py:128-184, waypoint_agent.py:81-242, hsa_agent.py:119-231,
  *                          attitude_agent.py:86-154, rate_agent.py:65-124}
+ *   fdyn_agent_step_*      {Rate,Attitude,HSA,Waypoint}Agent.compute_action (+ set_controls + step): one level commanded directly
  *   fdyn_rate_env_reset_*  RateControlEnv.reset              learned_controllers/envs/rate_env.py:151-210
  *   fdyn_rate_env_step_*   RateControlEnv.step (+ the vec-env's auto-reset, + optionally the PID demonstrator of
  *                          learned_controllers/utils/pid_demonstrations.py:47-77)
@@ -97,6 +98,23 @@ int fdyn_cascade_step_mixed(double* x, float* pid_state, int32_t* wp_idx, const 
 int fdyn_cascade_step_f32(float* x, float* pid_state, int32_t* wp_idx, const uint8_t* type, const double* params,
                           int n_types, const float* pid_cfg, const double* consts, const double* wps, int n_wp,
                           int64_t n, double dt, int n_steps, float* surf_out, int32_t* reached_total, void* stream);
+
+/* ---- one cascade level commanded directly --------------------------------------------------------------------------
+ * n_steps x {agent.compute_action(command, state, dt) -> set_controls -> one RK4 of dt}; n_steps == 0: compute_action only
+ * (x untouched).  level = FD_LEVEL_* ; cmd [4][n]: RATE p, q, r, throttle | ATTITUDE roll, pitch, yaw (NaN = no yaw
+ * command), throttle | HSA heading, speed, altitude, - | WAYPOINT north, east, altitude, speed (NaN = keep airspeed).
+ * Replaces RateAgent / AttitudeAgent / HSAAgent / WaypointAgent.compute_action (controllers/rate_agent.py:65-124,
+ * attitude_agent.py:86-154, hsa_agent.py:119-231, waypoint_agent.py:81-242) and the closed-loop helper the reference's tests
+ * use (tests/test_control_integration.py:34-74).  pid_state / pid_cfg / consts as fdyn_cascade_step_*.                    */
+int fdyn_agent_step_f64(int level, double* x, float* pid_state, const uint8_t* type, const double* params, int n_types,
+                        const float* pid_cfg, const double* consts, const double* cmd, int64_t n, double dt, int n_steps,
+                        double* surf_out, void* stream);
+int fdyn_agent_step_mixed(int level, double* x, float* pid_state, const uint8_t* type, const double* params, int n_types,
+                          const float* pid_cfg, const double* consts, const double* cmd, int64_t n, double dt, int n_steps,
+                          double* surf_out, void* stream);
+int fdyn_agent_step_f32(int level, float* x, float* pid_state, const uint8_t* type, const double* params, int n_types,
+                        const float* pid_cfg, const double* consts, const float* cmd, int64_t n, double dt, int n_steps,
+                        float* surf_out, void* stream);
 
 /* ---- rate-control env ------------------------------------------------------------------------------------------
  * x [FD_NX][n] ; e [FD_NE][n] (FD_E_*) ; ei [FD_NEI][n] int32 ; env_consts [FD_NEC] fp64 (FD_EC_*)

@@ -76,6 +76,8 @@ enum {
     FD_NC = 28
 };
 enum { FD_GUIDANCE_LOS = 0, FD_GUIDANCE_PP = 1, FD_GUIDANCE_DEFAULT = 2 };
+/* control levels, numbered as the reference's ControlMode (controllers/types.py:13-24): the level a command enters at */
+enum { FD_LEVEL_WAYPOINT = 1, FD_LEVEL_HSA = 2, FD_LEVEL_ATTITUDE = 3, FD_LEVEL_RATE = 4 };
 enum { FD_WP_NORTH = 0, FD_WP_EAST, FD_WP_ALTITUDE, FD_WP_SPEED, FD_NWP = 4 };  /* waypoint row */
 #define FD_MAX_WAYPOINTS 16
 
