@@ -157,3 +157,36 @@ def test_long_run_does_not_diverge_and_waypoint_level_runs():
     f.run(L.FD_LEVEL_WAYPOINT, np.array([300.0, 0.0, 100.0, 15.0]), 0.01, 1500)            # :688-743: flies towards the waypoint
     x = f.state_numpy()
     assert np.all(np.hypot(300.0 - x[:, 0], x[:, 1]) < 120.0) and np.all(np.abs(f.surfaces.cpu().numpy()) <= 1.0 + 1e-9)
+
+
+def test_cfg3_harness_through_single_aircraft_dropins():
+    """examples/03_waypoint_square_demo.py:148-209 written the reference's way -- get_state -> MissionPlanner.update ->
+    WaypointAgent.compute_action -> set_controls -> Simplified6DOF.step -- over the single-aircraft drop-in objects, first
+    1800 control steps (past the second waypoint): same arrival steps / distances and trajectory as the reference fixture."""
+    from hcrl_amd.backend import Simplified6DOF
+    from hcrl_amd.mission import MissionPlanner, MissionState
+    g = load_golden("cfg3_waypoint_square.npz")
+    fc = cfgmod.load_controller_config("cascaded_pid.yaml")
+    wps = [Waypoint.from_altitude(w[0], w[1], w[2], speed=w[3]) for w in g["waypoints"]]
+    mission = MissionPlanner(wps, acceptance_radius=float(g["radius"]))
+    assert mission.state == MissionState.IDLE and mission.get_waypoint_command() is None
+    mission.start()
+    agent = WaypointAgent(ControllerConfig(), "PP", fc)
+    sim = Simplified6DOF()
+    sim.reset(AircraftState.from_vector(g["x0"]))
+    dt, events = float(g["dt"]), []
+    for k in range(1800):
+        state = sim.get_state()
+        if mission.update(state):
+            events.append((k, mission.waypoints_reached - 1, mission.waypoint_distances[-1]))
+        cmd = mission.get_waypoint_command()
+        assert cmd is not None and cmd.mode == ControlMode.WAYPOINT
+        sim.set_controls(agent.compute_action(cmd, state, dt))
+        sim.step(dt)
+        if (k + 1) % 10 == 0 and (k + 1) // 10 < len(g["traj"]):
+            assert rel_err(sim.get_state().to_vector(), g["traj"][(k + 1) // 10], STATE_ANGLE_COLS).max() < 1e-6, k
+    want = g["events"][:2]
+    assert [e[0] for e in events] == [int(w[0]) for w in want] and [e[1] for e in events] == [int(w[2]) for w in want]
+    assert np.allclose([e[2] for e in events], want[:, 3], atol=1e-6)
+    assert mission.is_active() and abs(mission.get_progress_percentage() - 40.0) < 1e-9
+    assert abs(mission.get_total_mission_distance() - 1200.0) < 1e-9 and mission.get_summary()["waypoints_reached"] == 2
