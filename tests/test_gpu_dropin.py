@@ -5,6 +5,7 @@ import os
 import sys
 
 import numpy as np
+import torch
 import pytest
 
 from conftest import REPO, load_golden, rel_err, STATE_ANGLE_COLS
@@ -144,3 +145,42 @@ def test_fleet_recorder_writes_the_telemetry_format(tmp_path):
                                                                                       "angular_rate", "airspeed", "altitude"}
     x = fleet.state_numpy()[0]
     assert d["times"][-1] < fleet.time and abs(d["states"][-1]["altitude"] - 100.0) < 20.0 and np.isfinite(x).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f64", "mixed", "f32"])
+def test_reference_simulation_checks_as_one_fleet(precision):
+    """The qualitative checks of the reference's tests/test_simulation.py:46-223,425-461, one scenario per lane of ONE fleet:
+    default reset, descends without thrust, accelerates with thrust, elevator -> q, aileron -> p, finite over 1000 steps,
+    coarse dt = 0.1, 5 s open loop within (-200, 200) m and (0, 100) m/s."""
+    from hcrl_amd.fleet import BatchedSixDOF
+    f = BatchedSixDOF(5, precision)
+    f.reset()                                                     # default IC: 100 m, 20 m/s, level (:46-62)
+    x0 = f.state_numpy()
+    assert np.allclose(x0[:, 2], -100.0) and np.allclose(x0[:, 3], 20.0) and np.allclose(x0[:, 6:], 0.0)
+    u = np.zeros((5, 4))                                          # [elevator, aileron, rudder, throttle]
+    u[1, 3] = 1.0                                                 # lane 1: full thrust
+    u[2] = [0.5, 0.0, 0.0, 0.7]                                   # lane 2: nose-up elevator
+    u[3] = [0.0, 0.5, 0.0, 0.7]                                   # lane 3: aileron
+    u[4] = [0.02, 0.05, -0.02, 0.6]                               # lane 4: gentle open loop
+    f.set_controls(u)
+    for _ in range(50):
+        f.step(0.01)
+    x = f.state_numpy()
+    assert abs(x[2, 10]) > 0.01 and abs(x[3, 9]) > 0.01           # pitching / rolling (:151-185)
+    for _ in range(50):
+        f.step(0.01)
+    x = f.state_numpy()
+    d = f.derived().to(torch.float64).cpu().numpy()
+    assert -x[0, 2] < 100.0                                       # no thrust: descends (:113-130)
+    assert d[0, 1] > 20.0                                         # thrust: accelerates (:132-149)
+    assert abs(f.time - 1.0) < 1e-9                               # time advance (:98-111)
+    for _ in range(400):                                          # 5 s in all (:425-461)
+        f.step(0.01)
+    x = f.state_numpy()
+    assert np.isfinite(x).all() and np.all(np.abs(x[4, :3]) < 200.0) and 0.0 < np.linalg.norm(x[4, 3:6]) < 100.0
+    for _ in range(500):                                          # 1000 steps (:187-209)
+        f.step(0.01)
+    for _ in range(20):                                           # coarse steps (:211-223)
+        f.step(0.1)
+    assert np.isfinite(f.state_numpy()).all()
