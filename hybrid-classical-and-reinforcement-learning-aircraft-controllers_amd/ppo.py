@@ -40,7 +40,8 @@ class PPOConfig:
     vf_coef: float = 0.5
     max_grad_norm: float = 0.5
     normalize_advantage: bool = True
-    bootstrap_timeouts: bool = False
+    bootstrap_timeouts: object = False   # False | True (exact: V(terminal obs), host sync per step, no rollout graph) |
+                                         # "approx" (device-side, graph-safe: gamma * V(s_t) of the step that timed out)
     reward_scale: float = 1.0    # rewards are multiplied by this before GAE (1.0 = the reference's raw rewards; its -100 crash
                                  # penalty makes value targets O(100), so the shared grad-norm clip starves the actor at large batch)
 
@@ -167,7 +168,14 @@ class RecurrentPPO:
             self.buf_rew[t].copy_(rew)
             if cfg.reward_scale != 1.0:
                 self.buf_rew[t].mul_(cfg.reward_scale)
-            if cfg.bootstrap_timeouts:
+            if cfg.bootstrap_timeouts == "approx":
+                # time-limit truncation is not failure.  Partial-episode bootstrap without a second critic pass: the value the
+                # critic gave the observation this step started from stands in for V(terminal observation) (one 20 ms step
+                # earlier), as large-batch GPU trainers do; SB3 (which the reference uses) evaluates the terminal observation
+                # itself -- that is bootstrap_timeouts=True below, at the price of a host sync per step.
+                timeout = (trunc & ~term).float() if trunc.dtype == torch.bool else ((trunc != 0) & (term == 0)).float()
+                self.buf_rew[t].addcmul_(values, timeout, value=cfg.gamma)
+            elif cfg.bootstrap_timeouts:
                 # time-limit truncation is not failure: add gamma * V(s_T) (vec-env 'TimeLimit.truncated' handling).
                 # The post-step critic state belongs to the finished episode, so it can value the terminal observation.
                 ints, flts = env.episode_events()                     # host sync: this option disables graph replay
@@ -189,7 +197,7 @@ class RecurrentPPO:
     def collect_rollout(self):
         pol, cfg = self.policy, self.cfg
         pol.prepare_inference()                           # bf16 weight snapshot (refreshed IN PLACE) for the fused MFMA path
-        if self.use_graph and not cfg.bootstrap_timeouts and self.device.type == "cuda" and cfg.n_steps % 2 == 0:
+        if self.use_graph and cfg.bootstrap_timeouts in (False, "approx") and self.device.type == "cuda" and cfg.n_steps % 2 == 0:
             if self._graph is None or self._graph_env is not self.env:
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())

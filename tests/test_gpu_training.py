@@ -36,12 +36,29 @@ def test_ppo_iterations_run_and_stay_finite(dtype):
     assert 0 < ev["mean_length"] <= 500
 
 
-def test_timeout_bootstrap_path():
-    env = GpuRateVecEnv(256, "easy", 0.2, 0.02, "step", seed=2)      # 10-step episodes: every rollout sees truncations
+@pytest.mark.parametrize("mode", [True, "approx"])
+def test_timeout_bootstrap_path(mode):
+    """True: V(terminal observation) as SB3 does (host sync per step); "approx": gamma * V(s_t), device-side, inside the
+    rollout graph.  10-step episodes: every rollout sees truncations, and their rewards must have gained the bootstrap."""
+    env = GpuRateVecEnv(256, "easy", 0.2, 0.02, "step", seed=2)
     m = RecurrentPPO(env, RateLSTMPolicy(use_lstm=False), PPOConfig(n_steps=12, n_epochs=1, n_minibatches=2,
-                                                                     bootstrap_timeouts=True))
+                                                                     bootstrap_timeouts=mode))
     m.learn(256 * 12, log_interval=0)
     assert np.isfinite(m.last_stats["value_loss"])
+    plain = RecurrentPPO(GpuRateVecEnv(256, "easy", 0.2, 0.02, "step", seed=2), RateLSTMPolicy(use_lstm=False),
+                         PPOConfig(n_steps=12, n_epochs=1, n_minibatches=2), seed=0)
+    plain.policy.load_state_dict(m.policy.state_dict())
+    boot = RecurrentPPO(GpuRateVecEnv(256, "easy", 0.2, 0.02, "step", seed=2), RateLSTMPolicy(use_lstm=False),
+                        PPOConfig(n_steps=12, n_epochs=1, n_minibatches=2, bootstrap_timeouts=mode), seed=0)
+    boot.policy.load_state_dict(m.policy.state_dict())
+    for r in (plain, boot):
+        r.policy._noise_seed = 7
+        torch.manual_seed(5)
+        r.collect_rollout()
+    diff = boot.buf_rew - plain.buf_rew
+    assert torch.equal(boot.buf_act, plain.buf_act) and float(diff.abs().max()) > 0.0
+    timeouts = (boot.buf_start[1:] > 0)                               # an episode start at t+1 = an episode end at t
+    assert float(diff[:-1][~timeouts].abs().max()) == 0.0             # only steps that ended an episode were touched
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
