@@ -46,10 +46,10 @@ def test_timeout_bootstrap_path(mode):
     m.learn(256 * 12, log_interval=0)
     assert np.isfinite(m.last_stats["value_loss"])
     plain = RecurrentPPO(GpuRateVecEnv(256, "easy", 0.2, 0.02, "step", seed=2), RateLSTMPolicy(use_lstm=False),
-                         PPOConfig(n_steps=12, n_epochs=1, n_minibatches=2), seed=0)
+                         PPOConfig(n_steps=12, n_epochs=1, n_minibatches=2), seed=0, use_graph=False)
     plain.policy.load_state_dict(m.policy.state_dict())
     boot = RecurrentPPO(GpuRateVecEnv(256, "easy", 0.2, 0.02, "step", seed=2), RateLSTMPolicy(use_lstm=False),
-                        PPOConfig(n_steps=12, n_epochs=1, n_minibatches=2, bootstrap_timeouts=mode), seed=0)
+                        PPOConfig(n_steps=12, n_epochs=1, n_minibatches=2, bootstrap_timeouts=mode), seed=0, use_graph=False)
     boot.policy.load_state_dict(m.policy.state_dict())
     for r in (plain, boot):
         r.policy._noise_seed = 7
