@@ -475,8 +475,11 @@ rate_env_reset_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restric
     store_obs_tile(s_tile[wave], o, lane, obs_out, lm.wave_first, n, lpw);
 }
 
-template <typename S, typename T>
-__global__ void __launch_bounds__(FD_BLOCK)
+// OCC2: cap the registers at 256 so that two waves fit per SIMD.  At exactly one wave per SIMD (65 536 envs on 256 CUs) the
+// uncapped allocation (258 VGPRs) is 4 % faster; past that the second wave hides the first one's issue gaps
+// (1 Mi envs: 1.16e9 -> 1.56e9 env-steps/s).  The launcher picks by batch size; the arithmetic is the same.
+template <typename S, typename T, bool OCC2>
+__global__ void __launch_bounds__(FD_BLOCK, OCC2 ? 2 : 1)
 rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict__ eis,
                      const uint8_t* __restrict__ type, const double* __restrict__ params, int n_types,
                      const double* __restrict__ EC,
@@ -850,7 +853,15 @@ FD_DEFINE_CASCADE(fdyn_cascade_step_f32, float, float)
         if (!obs_out || !terminated || !truncated || !env_consts) return FDYN_ERR_NULL;                      \
         if (ev_count && (!ev_int || !ev_flt || ev_cap < 0)) return FDYN_ERR_NULL;                            \
         const int lpw = pick_lpw(n);                                                                         \
-        hipLaunchKernelGGL((rate_env_step_kernel<S, T>), dim3(grid_lpw(n, lpw)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
+        if (sizeof(T) == 4 && g_simds > 0 && n > int64_t(g_simds) * FD_WAVE)   /* pick_lpw has filled g_simds */   \
+            hipLaunchKernelGGL((rate_env_step_kernel<S, T, true>), dim3(grid_lpw(n, lpw)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
+                           x, e, ei, type, params, n_types, env_consts, actions, pid_state, pid_cfg,         \
+                           casc_consts, actions_out, rw_delta, pool, pool_depth, seed, auto_reset,           \
+                           residual_scale, obs_out,                                                          \
+                           reward_f32, reward_full, terminated, truncated, ev_count, ev_count_next, ev_int, ev_flt,  \
+                           ev_cap, n, lpw);                                                                  \
+        else                                                                                                 \
+            hipLaunchKernelGGL((rate_env_step_kernel<S, T, false>), dim3(grid_lpw(n, lpw)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
                            x, e, ei, type, params, n_types, env_consts, actions, pid_state, pid_cfg,         \
                            casc_consts, actions_out, rw_delta, pool, pool_depth, seed, auto_reset,           \
                            residual_scale, obs_out,                                                          \
