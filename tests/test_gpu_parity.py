@@ -369,3 +369,40 @@ def test_residual_env_f64_vs_fixture():
         assert abs(float(env.rewards_full[0]) - g["rewards"][k]) < 1e-6, k
         assert int(env.terminated[0]) == int(g["flags"][k, 0]) and int(env.truncated[0]) == int(g["flags"][k, 1])
         assert rel_err(env.obs.cpu().numpy()[0], g["obs"][k + 1]).max() < 1e-6, k
+
+
+def test_maximum_mission_length_and_type_count(oracle):
+    """Edge sizes: a 16-waypoint mission (FD_MAX_WAYPOINTS) flown by a fleet of 8 aircraft types (FD_MAX_TYPES), LOS
+    guidance, against the oracle per aircraft; one waypoint or one type too many is refused on the host and at the C-ABI."""
+    from hcrl_amd.flight_types import Waypoint
+    from hcrl_amd.params import AircraftParams as AP
+    ang = np.linspace(0, 2 * np.pi, 16, endpoint=False)
+    wps = [Waypoint.from_altitude(250 * np.cos(a), 250 * np.sin(a), 100 + 10 * np.sin(3 * a), speed=16.0) for a in ang]
+    types = [AP(mass=2.0 + 0.5 * k, max_thrust=30.0 + 4 * k) for k in range(8)]
+    n = 64
+    tidx = (np.arange(n) % 8).astype(np.uint8)
+    fc = cfgmod.load_controller_config("cascaded_pid.yaml")
+    c = BatchedCascade(n, wps, "f64", ControllerConfig(), fc, guidance_type="LOS", acceptance_radius=60.0, types=types, type_index=tidx)
+    x0 = np.zeros((n, 12)); x0[:, 0] = 250.0; x0[:, 2] = -100.0; x0[:, 3] = 16.0; x0[:, 8] = np.pi / 2
+    c.reset(x0)
+    c.run(0.01, 1500)
+    got, idx = c.state_numpy(), c.wp_idx.cpu().numpy()
+    assert idx.max() >= 2                                                       # the fleet is progressing round the circle
+    pc = cfgmod.pid_table(ControllerConfig(), fc)
+    Cc = cfgmod.cascade_consts(ControllerConfig(), fc, guidance_type="LOS", acceptance_radius=60.0)
+    W = np.ascontiguousarray(cfgmod.waypoint_table(wps))
+    for i in range(0, n, 5):
+        P = types[tidx[i]].to_block()
+        xs = np.ascontiguousarray(x0[i][:, None])
+        ps = np.zeros((L.FD_NPID * L.FD_NPS, 1), np.float32)
+        wi = np.zeros(1, np.int32)
+        oracle.lib.orc_cascade_step_batch(oracle.dp(P), oracle.fp(pc), oracle.fp(ps), oracle.dp(Cc), oracle.dp(W), 16, oracle.ip(wi),
+                                          oracle.dp(xs), None, 1, 0.01, 1500, 1)
+        assert wi[0] == idx[i] and rel_err(got[i], xs[:, 0], STATE_ANGLE_COLS).max() < 1e-6, i
+    with pytest.raises(ValueError):
+        cfgmod.waypoint_table(wps + wps[:1])
+    rc = c.lib.fdyn_cascade_step_f64(c.x.data_ptr(), c.pid_state.data_ptr(), c.wp_idx.data_ptr(), None, c.params.data_ptr(), 1,
+                                     c.pid_cfg.data_ptr(), c.consts.data_ptr(), c.wps.data_ptr(), 17, n, 0.01, 1, None, None, None)
+    assert rc == -3                                                             # FDYN_ERR_BAD_SIZE
+    rc = c.lib.fdyn_sixdof_step_f64(c.x.data_ptr(), c.u.data_ptr(), None, c.params.data_ptr(), 9, n, 0.01, 1, None, None)
+    assert rc == -2                                                             # FDYN_ERR_BAD_TYPES
