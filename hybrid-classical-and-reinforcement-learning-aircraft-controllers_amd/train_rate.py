@@ -33,13 +33,20 @@ def main(argv=None):
     ap.add_argument("--resume", type=str, default=None, help="checkpoint (RecurrentPPO.save) to continue from")
     ap.add_argument("--callbacks", action="store_true",
                     help="periodic evaluation (best model, evaluations.npz) and checkpoints per the config's eval_freq / save_freq")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend under torch.distributed.run (nccl = RCCL over xGMI; gloo for rehearsals)")
+    ap.add_argument("--device-index", type=int, default=-1, help="force every rank onto this GPU (one-GPU rehearsal of N > 1)")
     args = ap.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
+    dev_index = args.device_index if args.device_index >= 0 else local
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
     rank = dist.get_rank() if world > 1 else 0
 
     config = load_config(args.config)
