@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--policy-dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU-side rendezvous for rehearsals")
     ap.add_argument("--device-index", type=int, default=-1, help="force every rank onto this GPU (1-GPU rehearsal of N>1)")
+    ap.add_argument("--physics-substeps", type=int, default=1,
+                    help="physics workload: RK4 sub-steps of 1 ms fused per launch (1 = Simplified6DOF.step(0.01); 20 = the env's backend step)")
     ap.add_argument("--ppo-steps", type=int, default=16, help="rollout length per PPO iteration (train workload)")
     ap.add_argument("--ppo-epochs", type=int, default=2)
     ap.add_argument("--ppo-minibatches", type=int, default=2)
@@ -118,8 +120,10 @@ class Workload:
             u = np.concatenate([rs.uniform(-0.3, 0.3, (n, 3)), rs.uniform(0.3, 0.9, (n, 1))], 1)
             self.fleet = BatchedSixDOF(n, prec)
             self.fleet.reset(x0); self.fleet.set_controls(u)
-            self.units_per_step = n
-            self.desc = f"Simplified6DOF.step(0.01), one RK4 per launch, {n} aircraft/GPU"
+            self.n_sub = int(getattr(args, "physics_substeps", 1))
+            self.units_per_step = n * self.n_sub
+            self.desc = (f"Simplified6DOF.step(0.01), one RK4 per launch, {n} aircraft/GPU" if self.n_sub == 1 else
+                         f"SimulationAircraftBackend.step(0.02) = {self.n_sub} RK4 sub-steps of 1 ms per launch, {n} aircraft/GPU")
         else:
             fc = cfgmod.load_controller_config("cascaded_pid.yaml")
             mc = cfgmod.load_mission_config("square_pattern.yaml")
@@ -158,7 +162,10 @@ class Workload:
         elif self.kind == "env_pid":
             self.env.step_device(None)
         elif self.kind == "physics":
-            self.fleet.step(0.01)
+            if self.n_sub == 1:
+                self.fleet.step(0.01)
+            else:
+                self.fleet.step(0.001 * self.n_sub, 0.001)
         else:
             self.fleet.run(0.01, self.inner)
 
@@ -220,6 +227,7 @@ def extras(args):
     # saturation throughput"): 4 Mi aircraft / 1 Mi envs per GPU -- what the hardware sustains once launch cost is amortised
     for key, wl_name, steps, warm, batch in (("physics", "physics", 400, 40, None), ("cascade", "cascade", 100, 10, None),
                                              ("rollout", "rollout", 60, 6, None), ("train", "train", 2, 1, None),
+                                             ("physics_20_substeps", "physics", 200, 20, None),
                                              ("physics_saturation", "physics", 100, 10, 1 << 22),
                                              ("env_saturation", "env", 60, 6, 1 << 20)):
         try:
@@ -227,6 +235,7 @@ def extras(args):
             a.workload, a.steps, a.warmup = wl_name, steps, warm
             if batch is not None:
                 a.batch = batch
+            a.physics_substeps = 20 if key == "physics_20_substeps" else 1
             wl = Workload(a, 0)
             wall, dev_ms, mode = timed_region(wl, a, 1)
             wl_name = key
