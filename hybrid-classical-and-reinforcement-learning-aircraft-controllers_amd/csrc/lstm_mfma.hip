@@ -61,11 +61,8 @@ __device__ __forceinline__ void wait_vmcnt_le(int n)       // n in {0, 4, 6}: th
 __device__ __forceinline__ float sigmoid_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanh_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
 __device__ __forceinline__ uint16_t f2bf(float f)
-{
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return uint16_t((u >> 16) | 0x40);      // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);                                               // round to nearest even
-    return uint16_t(u >> 16);
+{   // round-to-nearest-even, NaN stays NaN: one v_cvt_pk_bf16_f32 on gfx950 (the shift/add/select form costs six VALU ops)
+    return __builtin_bit_cast(uint16_t, static_cast<__bf16>(f));
 }
 
 // KX = input width, KH = recurrent width (0 = zero-state layer: no h input, no c_prev, no forget gate).
