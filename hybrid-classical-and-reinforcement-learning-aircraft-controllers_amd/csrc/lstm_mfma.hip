@@ -60,6 +60,9 @@ __device__ __forceinline__ void wait_vmcnt_le(int n)       // n in {0, 4, 6}: th
 
 __device__ __forceinline__ float sigmoid_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanh_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
+// the same two functions of (acc + bias) with the bias folded into the exponent's FMA: sb = -bias * log2(e), tb = 2 bias log2(e)
+__device__ __forceinline__ float sigmoid_b(float acc, float sb) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(acc, -1.4426950408889634f, sb))); }
+__device__ __forceinline__ float tanh_b(float acc, float tb) { return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(__builtin_fmaf(acc, 2.8853900817779268f, tb)) + 1.0f), 1.0f); }
 __device__ __forceinline__ uint16_t f2bf(float f)
 {   // round-to-nearest-even, NaN stays NaN: one v_cvt_pk_bf16_f32 on gfx950 (the shift/add/select form costs six VALU ops)
     return __builtin_bit_cast(uint16_t, static_cast<__bf16>(f));
@@ -381,11 +384,11 @@ lstm_cell_mfma_dma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const
             }
             // C/D map of a 32x32 tile: col = lane & 31 (hidden unit), row = (e & 3) + 8 (e >> 2) + 4 hf
             if (pass == 0) {
-                const float bi = bias[col], bg = bias[2 * H + col];
+                const float bi = bias[col] * -1.4426950408889634f, bg = bias[2 * H + col] * 2.8853900817779268f;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) ig[e] = sigmoid_(acc0[e] + bi) * tanh_(acc1[e] + bg);
+                for (int e = 0; e < 16; ++e) ig[e] = sigmoid_b(acc0[e], bi) * tanh_b(acc1[e], bg);
             } else {
-                const float bo = bias[3 * H + col], bf = RECUR ? bias[H + col] : 0.0f;
+                const float bo = bias[3 * H + col] * -1.4426950408889634f, bf = RECUR ? bias[H + col] * -1.4426950408889634f : 0.0f;
                 // Addresses: [per-wave base pointer] + [one 32-bit per-lane offset] + [compile-time row constant * H].
                 // Written as b * H + col per element, LLVM hoists sixteen 64-bit row addresses per output array out of
                 // the slice loop and the activation slab spills.
@@ -406,8 +409,8 @@ lstm_cell_mfma_dma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const
                     const int off = lane_off + ((e & 3) + 8 * (e >> 2)) * H;
                     float c = ig[e];
                     float go;
-                    if (RECUR) c += sigmoid_(acc0[e] + bf) * (s_keep[wave * 32 + lr] * cp[e]);
-                    go = sigmoid_(acc1[e] + bo);
+                    if (RECUR) c += sigmoid_b(acc0[e], bf) * (s_keep[wave * 32 + lr] * cp[e]);
+                    go = sigmoid_b(acc1[e], bo);
                     const float hv = go * tanh_(c);
                     if (full || lr < rows_left) {
                         if (c_out) c_out[wave_off + off] = c;
