@@ -396,26 +396,55 @@ lstm_cell_mfma_dma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const
                 const int lane_off = hf * 4 * H + col;
                 const int64_t wave_off = (row0 < B ? row0 : 0) * H;      // a wave wholly past B reads row 0, stores nothing
                 const int rows_left = row0 < B ? int(B - row0 < 32 ? B - row0 : 32) : 0;   // rows of this tile that exist
+                // Uniform base pointers + UNSIGNED 32-bit lane offsets: the loads / stores take the "scalar base + vector offset"
+                // form (as signed ints every one of the 64 accesses paid a 64-bit shift-add pair), and the wave-uniform `full`
+                // picks a branch-free store sequence for every tile except the batch's ragged last one.
+                // (row0 recomputed from the readfirstlane'd wave index: the compiler then knows the bases are wave-uniform -> SGPRs)
+                const int64_t urow0 = int64_t(blockIdx.x) * BM + uwave * 32;
+                const int64_t uwave_off = (urow0 < B ? urow0 : 0) * H;
+                const float* cp_base = RECUR ? c_prev + uwave_off : nullptr;
+                float* c_base = c_out ? c_out + uwave_off : nullptr;
+                float* h32_base = h_out_f32 ? h_out_f32 + uwave_off : nullptr;
+                uint16_t* h_base = h_out + uwave_off;
+                const uint32_t uoff = uint32_t(lane_off), uH = uint32_t(H), ucol = uint32_t(col);
+                // BYTE offsets in 32 bits (a 32-row tile spans < 64 KB): with element indices the compiler must widen before scaling
+                auto ld_f32 = [](const float* b, uint32_t boff) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(b) + boff); };
+                auto st_f32 = [](float* b, uint32_t boff, float v) { *reinterpret_cast<float*>(reinterpret_cast<char*>(b) + boff) = v; };
+                auto st_u16 = [](uint16_t* b, uint32_t boff, uint16_t v) { *reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(b) + boff) = v; };
                 float cp[16];                                 // all 16 c_prev loads issued together (clamped row)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int lr = (e & 3) + 8 * (e >> 2) + 4 * hf;
-                    const int off = (full || lr < rows_left) ? lane_off + ((e & 3) + 8 * (e >> 2)) * H : col;
-                    cp[e] = RECUR ? c_prev[wave_off + off] : 0.0f;
+                    const uint32_t off = (full || lr < rows_left) ? uoff + uint32_t((e & 3) + 8 * (e >> 2)) * uH : ucol;
+                    cp[e] = RECUR ? ld_f32(cp_base, off * 4u) : 0.0f;
                 }
+                float cv[16], hv[16];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int lr = (e & 3) + 8 * (e >> 2) + 4 * hf;
-                    const int off = lane_off + ((e & 3) + 8 * (e >> 2)) * H;
                     float c = ig[e];
-                    float go;
                     if (RECUR) c += sigmoid_b(acc0[e], bf) * (s_keep[wave * 32 + lr] * cp[e]);
-                    go = sigmoid_b(acc1[e], bo);
-                    const float hv = go * tanh_(c);
-                    if (full || lr < rows_left) {
-                        if (c_out) c_out[wave_off + off] = c;
-                        h_out[wave_off + off] = f2bf(hv);
-                        if (h_out_f32) h_out_f32[wave_off + off] = hv;
+                    cv[e] = c;
+                    hv[e] = sigmoid_b(acc1[e], bo) * tanh_(c);
+                }
+                if (full) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const uint32_t off = uoff + uint32_t((e & 3) + 8 * (e >> 2)) * uH;
+                        if (c_base) st_f32(c_base, off * 4u, cv[e]);
+                        st_u16(h_base, off * 2u, f2bf(hv[e]));
+                        if (h32_base) st_f32(h32_base, off * 4u, hv[e]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int lr = (e & 3) + 8 * (e >> 2) + 4 * hf;
+                        const uint32_t off = uoff + uint32_t((e & 3) + 8 * (e >> 2)) * uH;
+                        if (lr < rows_left) {
+                            if (c_base) st_f32(c_base, off * 4u, cv[e]);
+                            st_u16(h_base, off * 2u, f2bf(hv[e]));
+                            if (h32_base) st_f32(h32_base, off * 4u, hv[e]);
+                        }
                     }
                 }
             }
