@@ -301,10 +301,12 @@ def main():
     per_launch_s = dev_ms * 1e-3 / K
     alg_bytes = ALG_BYTES[args.workload] * wl.units_per_step
     achieved = alg_bytes / per_launch_s / 1e9
-    traffic = None
+    traffic, valu = None, None
     tpath = os.path.join(REPO, "profiles", "traffic.json")           # PMC-derived HBM bytes per launch, if collected
     if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get(f"{args.workload}_{args.precision}_{args.batch}")
+        tj = json.load(open(tpath))
+        traffic = tj.get(f"{args.workload}_{args.precision}_{args.batch}")
+        valu = tj.get(f"{args.workload}_{args.precision}_{args.batch}_valu")      # VALU-pipe occupancy from the same PMC runs
     out = {
         "metric": "env-steps/sec (whole node), rate-control task, batch 65536 per GPU" if args.workload.startswith("env")
                   else f"{args.workload} aircraft-steps/sec",
@@ -321,7 +323,8 @@ def main():
                      "note": "kernel is vector-ALU bound (AI ~ 133 flop/B); see compute"},
         "compute": {"achieved_tflops": ALG_FLOPS[args.workload] * wl.units_per_step / per_launch_s / 1e12,
                     "peak_tflops": FP32_VECTOR_PEAK_TFLOPS,
-                    "frac": ALG_FLOPS[args.workload] * wl.units_per_step / per_launch_s / 1e12 / FP32_VECTOR_PEAK_TFLOPS},
+                    "frac": ALG_FLOPS[args.workload] * wl.units_per_step / per_launch_s / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+                    "valu_pmc": valu},
     }
     if args.workload in ("rollout", "train"):
         mult = 1.0 if args.workload == "rollout" else (1.0 + 3.0 * args.ppo_epochs)      # fwd, or fwd + epochs x (fwd+bwd)
