@@ -266,7 +266,9 @@ class RecurrentPPO:
                 try:
                     ug = self._update_graph = self._build_update_graph(mb)
                 except Exception as e:                    # capture is an optimisation: fall back to the eager loop, loudly
-                    print(f"[ppo] update-graph capture failed ({type(e).__name__}: {e}); running the update eagerly", flush=True)
+                    import sys
+                    print(f"[ppo] update-graph capture failed ({type(e).__name__}: {e}); running the update eagerly",
+                          file=sys.stderr, flush=True)
                     self.use_update_graph, ug = False, None
                     torch.cuda.synchronize()
         for _ in range(cfg.n_epochs):
