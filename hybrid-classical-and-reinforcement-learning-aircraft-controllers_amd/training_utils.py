@@ -81,9 +81,16 @@ def behavior_cloning_pretrain(model, observations, actions, epochs=10, batch_siz
 
 
 @torch.no_grad()
-def run_final_evaluation(model, difficulty="hard", n_episodes=10, dt=0.02, seed=0):
+def load_demonstrations(path: str) -> Tuple[np.ndarray, np.ndarray]:
+    """pid_demonstrations.py:113-127 for the data-only .npz this package writes (the reference pickles a dict)."""
+    d = np.load(path)
+    return d["observations"], d["actions"]
+
+
+def run_final_evaluation(model, difficulty="hard", n_episodes=10, dt=0.02, seed=0, residual_scale=0.0):
     """training_utils.py:216-249: deterministic policy, one episode per env, mean length and return."""
-    env = GpuRateVecEnv(n_episodes, difficulty, 10.0, dt, "step", seed=seed, precision="mixed", sampling="device")
+    env = GpuRateVecEnv(n_episodes, difficulty, 10.0, dt, "step", seed=seed, precision="mixed", sampling="device",
+                        residual_scale=residual_scale)
     obs = env.reset().clone()
     pol = model.policy
     st = pol.initial_state(n_episodes, env.device)
@@ -129,8 +136,9 @@ class EvalCallback:
     the best mean reward so far kept as `<best_model_save_path>/best_model.pt`."""
 
     def __init__(self, difficulty: str, best_model_save_path: str, log_path: str, eval_freq: int, n_eval_episodes: int = 10,
-                 deterministic: bool = True):
+                 deterministic: bool = True, residual_scale: float = 0.0):
         self.difficulty, self.best_dir, self.log_dir = difficulty, best_model_save_path, log_path
+        self.residual_scale = residual_scale
         self.eval_freq, self.n_eval_episodes, self.deterministic = max(int(eval_freq), 1), n_eval_episodes, deterministic
         self._last, self.best_mean_reward = 0, -float("inf")
         self.timesteps, self.results, self.ep_lengths = [], [], []
@@ -140,7 +148,8 @@ class EvalCallback:
         if n_calls // self.eval_freq <= self._last:
             return
         self._last = n_calls // self.eval_freq
-        ev = run_final_evaluation(model, difficulty=self.difficulty, n_episodes=self.n_eval_episodes)
+        ev = run_final_evaluation(model, difficulty=self.difficulty, n_episodes=self.n_eval_episodes,
+                                  residual_scale=self.residual_scale)
         self.timesteps.append(model.num_timesteps); self.results.append(ev["rewards"]); self.ep_lengths.append(ev["lengths"])
         os.makedirs(self.log_dir, exist_ok=True)
         np.savez(os.path.join(self.log_dir, "evaluations.npz"), timesteps=np.array(self.timesteps),

@@ -406,3 +406,18 @@ def test_update_graph_replays_match_eager_at_training_size():
             off += p.numel()
             err = float((a - b).norm() / (b.norm() + 1e-9))
             assert err < 2e-2 and bool(torch.isfinite(a).all()), (trial, n, err)
+
+
+@pytest.mark.parametrize("residual", [False, True])
+def test_train_with_imitation_cli(tmp_path, residual):
+    """train_with_imitation.py:51-199 end to end on a tiny budget: demonstrations -> BC -> PPO (optionally on the residual env)
+    -> checkpoints + evaluation."""
+    from hcrl_amd import train_with_imitation as twi
+    argv = ["--n-demos", "64", "--bc-epochs", "2", "--rl-steps", str(512 * 16 * 3), "--n-envs", "512", "--n-steps", "16",
+            "--model-dir", str(tmp_path / "m"), "--demo-path", str(tmp_path / "demos.npz")] + (["--residual"] if residual else [])
+    ev = twi.main(argv)
+    assert np.isfinite(ev["mean_reward"]) and 0 < ev["mean_length"] <= 500
+    assert (tmp_path / "m" / "final_model.pt").exists() and (tmp_path / "m" / "bc_pretrained.pt").exists()
+    assert (tmp_path / "demos.npz").exists()
+    ev2 = twi.main(argv + ["--rl-steps", str(512 * 16)])          # second run re-uses the stored demonstrations
+    assert np.isfinite(ev2["mean_reward"])
