@@ -15,6 +15,7 @@ import torch.distributed as dist
 from .policy import RateLSTMPolicy
 from .ppo import PPOConfig, RecurrentPPO
 from .training_utils import (behavior_cloning_pretrain, collect_pid_demonstrations, create_callbacks, create_vec_env, load_config,
+                             normalize_config,
                              run_final_evaluation)
 
 DEFAULT_CONFIG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs", "training", "ppo_lstm.yaml")
@@ -49,7 +50,7 @@ def main(argv=None):
             dist.init_process_group("gloo")
     rank = dist.get_rank() if world > 1 else 0
 
-    config = load_config(args.config)
+    config = normalize_config(load_config(args.config))
     for item in args.set:                                   # SECTION.KEY=VALUE overrides (YAML-typed values)
         import yaml as _yaml
         key, val = item.split("=", 1)
@@ -78,9 +79,13 @@ def main(argv=None):
             print(f"resumed from {args.resume} at {model.num_timesteps} timesteps")
     callback = create_callbacks(config) if (args.callbacks and rank == 0) else None
 
-    if args.bc_pretrain and rank == 0:
-        obs, acts = collect_pid_demonstrations(n_episodes=2048, difficulty="medium", seed=seed)
-        print("BC losses:", behavior_cloning_pretrain(model, obs, acts, epochs=args.bc_pretrain))
+    imit = config.get("imitation")                          # train_overnight-style files carry their own imitation settings
+    if (args.bc_pretrain or (imit and not args.resume)) and rank == 0:
+        obs, acts = collect_pid_demonstrations(n_episodes=imit["n_episodes"] if (imit and not args.bc_pretrain) else 2048,
+                                               difficulty=imit["difficulty"] if (imit and not args.bc_pretrain) else "medium", seed=seed)
+        kw = dict(epochs=args.bc_pretrain) if args.bc_pretrain else dict(epochs=imit["epochs"], batch_size=imit["batch_size"],
+                                                                         lr=imit["learning_rate"])
+        print("BC losses:", behavior_cloning_pretrain(model, obs, acts, **kw))
     if world > 1:
         from .ppo import broadcast_parameters
         broadcast_parameters(model.policy)

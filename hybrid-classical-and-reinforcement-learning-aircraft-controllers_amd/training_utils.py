@@ -17,6 +17,58 @@ def load_config(config_path: str) -> dict:
         return yaml.safe_load(f)
 
 
+def normalize_config(config: dict) -> dict:
+    """Bring either of the reference's two YAML schemas to the one `train_rate` reads.
+
+    `train_rate.py`-style files (config/ppo_lstm.yaml, fast_mlp_training.yaml, quick_test.yaml ...) only get defaults for
+    sections they omit (e.g. `lstm: {enabled: false}` without sizes).  `train_overnight.py`-style files
+    (config/overnight_v2.yaml: `network`, `parallel`, `logging`, `checkpointing`, `approach`, `demonstrations`,
+    `behavior_cloning`; train_overnight.py:53-193) are mapped onto the same keys, and their imitation settings are returned
+    under `imitation` so the trainer can apply them."""
+    c = dict(config)
+    net = c.get("network", {})
+    lstm = dict(c.get("lstm", {}))
+    if "enabled" not in lstm:
+        lstm["enabled"] = net.get("type", "lstm" if "lstm" in c else "mlp") == "lstm"
+    lstm.setdefault("lstm_hidden_size", net.get("lstm", {}).get("hidden_size", 256))
+    lstm.setdefault("n_lstm_layers", net.get("lstm", {}).get("n_layers", 2))
+    lstm.setdefault("features_dim", 128)
+    c["lstm"] = lstm
+    mlp = dict(c.get("mlp", {}))
+    mlp.setdefault("net_arch", net.get("mlp", {}).get("net_arch", [256, 128, 64]))
+    c["mlp"] = mlp
+    cur = dict(c.get("curriculum", {}))
+    cur.setdefault("phases", [])
+    cur.setdefault("enabled", bool(cur["phases"]) and c.get("approach", {}).get("use_curriculum", True))
+    c["curriculum"] = cur
+    env = dict(c.get("environment", {}))
+    first = cur["phases"][0] if cur["phases"] else {}
+    env.setdefault("difficulty", first.get("difficulty", "medium"))
+    env.setdefault("command_type", first.get("command_type", "step"))
+    env.setdefault("episode_length", 10.0)
+    env.setdefault("dt", 0.02)
+    c["environment"] = env
+    tr = dict(c.get("training", {}))
+    tr.setdefault("n_envs", c.get("parallel", {}).get("n_envs", 4))
+    tr.setdefault("log_interval", c.get("logging", {}).get("log_interval", 10))
+    tr.setdefault("eval_freq", c.get("evaluation", {}).get("eval_freq", 10000))
+    tr.setdefault("save_freq", c.get("checkpointing", {}).get("save_freq", 50000))
+    tr.setdefault("total_timesteps", sum(p["timesteps"] for p in cur["phases"]) or 1000000)
+    c["training"] = tr
+    paths = dict(c.get("paths", {}))
+    paths.setdefault("model_save_dir", paths.get("model_dir", "runs/checkpoints"))
+    paths.setdefault("tensorboard_log", "runs/tensorboard")
+    paths.setdefault("best_model_path", paths.get("best_model", "runs/best_rate_controller"))
+    c["paths"] = paths
+    c.setdefault("seed", 42)
+    if c.get("approach", {}).get("use_imitation"):
+        demo, bc = c.get("demonstrations", {}), c.get("behavior_cloning", {})
+        c["imitation"] = {"n_episodes": demo.get("n_episodes", 100), "difficulty": demo.get("difficulty", "medium"),
+                          "epochs": bc.get("epochs", 10), "batch_size": bc.get("batch_size", 256),
+                          "learning_rate": bc.get("learning_rate", 1e-3)}
+    return c
+
+
 def create_vec_env(config: dict, n_envs: int = 4, seed: Optional[int] = None, **kw) -> GpuRateVecEnv:
     """training_utils.py:49-69: same arguments; returns ONE device-resident vec-env instead of n_envs subprocesses.
     Env `i` is seeded `seed + i` like `make_env(config, rank=i, seed)` (:41)."""

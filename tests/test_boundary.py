@@ -162,3 +162,46 @@ def test_alias_imports_are_the_same_module_objects():
         importlib.import_module(f"hcrl_amd.{sub}")
         assert sys.modules[f"hcrl_amd.{sub}"] is importlib.import_module(f"{real}.{sub}"), sub
     assert A is importlib.import_module(f"{real}.flight_types").ControlMode
+
+
+def test_both_reference_yaml_schemas_normalize_to_the_trainer_schema():
+    """train_rate.py-style files with omitted sections and train_overnight.py-style files (network / parallel / logging /
+    checkpointing / approach / demonstrations / behavior_cloning) end up with the keys hcrl_amd.train_rate reads."""
+    import yaml
+    from hcrl_amd.training_utils import normalize_config
+    from hcrl_amd.ppo import PPOConfig
+    a = normalize_config(yaml.safe_load("""
+environment: {difficulty: medium, episode_length: 10.0, dt: 0.02, command_type: step}
+training: {total_timesteps: 1000000, n_envs: 8, eval_freq: 50000, save_freq: 200000, log_interval: 10}
+curriculum: {enabled: true, phases: [{name: medium, difficulty: medium, timesteps: 500000, command_type: step}]}
+ppo: {learning_rate: 3.0e-4, n_steps: 1024, batch_size: 256, n_epochs: 5, gamma: 0.99}
+lstm: {enabled: false}
+mlp: {net_arch: [128, 128]}
+paths: {model_save_dir: m, tensorboard_log: t, best_model_path: b}
+"""))
+    assert a["lstm"] == {"enabled": False, "lstm_hidden_size": 256, "n_lstm_layers": 2, "features_dim": 128}
+    assert a["mlp"]["net_arch"] == [128, 128] and a["curriculum"]["enabled"] and "imitation" not in a
+    b = normalize_config(yaml.safe_load("""
+approach: {use_imitation: true, use_residual: false, use_curriculum: true}
+demonstrations: {n_episodes: 500, difficulty: easy, save_path: x.pkl}
+behavior_cloning: {epochs: 20, batch_size: 256, learning_rate: 0.001}
+curriculum:
+  phases:
+    - {name: easy, difficulty: easy, timesteps: 3000000, command_type: step}
+    - {name: hard_mixed, difficulty: hard, timesteps: 8000000, command_type: random}
+environment: {episode_length: 10.0, dt: 0.02}
+ppo: {learning_rate: 0.0003, n_steps: 2048, batch_size: 256, n_epochs: 10, gamma: 0.99, gae_lambda: 0.95, clip_range: 0.2,
+      ent_coef: 0.01, vf_coef: 0.5, max_grad_norm: 0.5}
+network: {type: mlp, mlp: {net_arch: [256, 256, 128]}, lstm: {hidden_size: 256, n_layers: 2}}
+parallel: {n_envs: 8, vec_env_type: subproc}
+evaluation: {eval_freq: 100000, n_eval_episodes: 10, deterministic: true}
+checkpointing: {save_freq: 500000, keep_last_n: 5}
+paths: {model_dir: md, tensorboard_log: tb, best_model: best}
+logging: {log_interval: 10, verbose: 1}
+seed: 42
+"""))
+    assert b["lstm"]["enabled"] is False and b["mlp"]["net_arch"] == [256, 256, 128] and b["training"]["n_envs"] == 8
+    assert b["training"]["total_timesteps"] == 11000000 and b["curriculum"]["enabled"] and b["environment"]["difficulty"] == "easy"
+    assert b["training"]["save_freq"] == 500000 and b["training"]["eval_freq"] == 100000 and b["paths"]["model_save_dir"] == "md"
+    assert b["imitation"] == {"n_episodes": 500, "difficulty": "easy", "epochs": 20, "batch_size": 256, "learning_rate": 0.001}
+    assert PPOConfig.from_dict(b["ppo"]).n_steps == 2048

@@ -421,3 +421,34 @@ def test_train_with_imitation_cli(tmp_path, residual):
     assert (tmp_path / "demos.npz").exists()
     ev2 = twi.main(argv + ["--rl-steps", str(512 * 16)])          # second run re-uses the stored demonstrations
     assert np.isfinite(ev2["mean_reward"])
+
+
+def test_train_rate_accepts_the_overnight_schema(tmp_path):
+    """A train_overnight.py-style YAML (network / parallel / approach / demonstrations ...) through train_rate: imitation from
+    the file's own settings, MLP policy, two curriculum phases."""
+    import yaml
+    from hcrl_amd import train_rate
+    cfg = yaml.safe_load("""
+approach: {use_imitation: true, use_residual: false, use_curriculum: true}
+demonstrations: {n_episodes: 64, difficulty: easy, save_path: unused.pkl}
+behavior_cloning: {epochs: 2, batch_size: 256, learning_rate: 0.001}
+curriculum:
+  phases:
+    - {name: easy, difficulty: easy, timesteps: 8192, command_type: step}
+    - {name: hard_mixed, difficulty: hard, timesteps: 8192, command_type: random}
+environment: {episode_length: 10.0, dt: 0.02}
+ppo: {learning_rate: 0.0003, n_steps: 16, batch_size: 256, n_epochs: 1, gamma: 0.99, gae_lambda: 0.95, clip_range: 0.2,
+      ent_coef: 0.01, vf_coef: 0.5, max_grad_norm: 0.5}
+network: {type: mlp, mlp: {net_arch: [64, 64]}, lstm: {hidden_size: 256, n_layers: 2}}
+parallel: {n_envs: 512, vec_env_type: subproc}
+evaluation: {eval_freq: 100000, n_eval_episodes: 4, deterministic: true}
+checkpointing: {save_freq: 500000, keep_last_n: 5}
+logging: {log_interval: 10, verbose: 1}
+seed: 7
+""")
+    cfg["paths"] = {"model_dir": str(tmp_path / "m"), "tensorboard_log": str(tmp_path / "tb"), "best_model": str(tmp_path / "best")}
+    p = tmp_path / "overnight.yaml"
+    p.write_text(yaml.safe_dump(cfg))
+    train_rate.main(["--config", str(p)])
+    ck = torch.load(tmp_path / "m" / "final_model.pt", weights_only=True)
+    assert ck["num_timesteps"] == 2 * 8192 and not any(k.startswith("lstm_actor") for k in ck["policy"])
