@@ -56,6 +56,7 @@ class AgentFleet(BatchedSixDOF):
                  flight_config: Optional[FlightControlConfig] = None, guidance_type: str = "LOS", **kw):
         super().__init__(n, precision, **kw)
         self.pid_cfg = torch.as_tensor(pid_table(config, flight_config), device=self.device)
+        self.cfg_per_lane = 0
         self.consts = torch.as_tensor(cascade_consts(config, flight_config, guidance_type), device=self.device)
         self.pid_state = torch.zeros((L.FD_NPID * L.FD_NPS, self.n), dtype=torch.float32, device=self.device)
         self.surfaces = torch.zeros((L.FD_NU, self.n), dtype=self.dtype, device=self.device)
@@ -63,6 +64,12 @@ class AgentFleet(BatchedSixDOF):
 
     def reset_agents(self):
         self.pid_state.zero_()
+
+    def set_gain_tables(self, tables):
+        """One PID table per aircraft ([N][FD_NPID][FD_NPC] float32, rows as config.pid_table): a gain sweep in one launch."""
+        t = torch.as_tensor(np.asarray(tables, np.float32), device=self.device).contiguous()
+        assert t.shape == (self.n, L.FD_NPID, L.FD_NPC)
+        self.pid_cfg, self.cfg_per_lane = t, 1
 
     def _cmd(self, cmd):
         c = torch.as_tensor(cmd, dtype=self.dtype, device=self.device)
@@ -74,7 +81,7 @@ class AgentFleet(BatchedSixDOF):
     def _launch(self, level, cmd, dt, n_steps):
         c = self._cmd(cmd)
         rc = self._agent_fn(int(level), _lib.ptr(self.x), _lib.ptr(self.pid_state), _lib.ptr(self.type_index), _lib.ptr(self.params),
-                            self.n_types, _lib.ptr(self.pid_cfg), _lib.ptr(self.consts), _lib.ptr(c), self.n, float(dt),
+                            self.n_types, _lib.ptr(self.pid_cfg), self.cfg_per_lane, _lib.ptr(self.consts), _lib.ptr(c), self.n, float(dt),
                             int(n_steps), _lib.ptr(self.surfaces), _lib.current_stream())
         _lib.check(rc, "agent step")
 

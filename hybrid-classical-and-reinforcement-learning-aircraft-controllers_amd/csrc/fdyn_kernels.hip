@@ -214,13 +214,13 @@ __global__ void __launch_bounds__(FD_BLOCK)
 agent_step_kernel(int level, S* __restrict__ xs, float* __restrict__ pid_state /*[9*3][n]*/, const uint8_t* __restrict__ type,
                   const double* __restrict__ params, int n_types, const float* __restrict__ pid_cfg,
                   const double* __restrict__ consts, const S* __restrict__ cmd /*[4][n]*/, int64_t n, S dt, int n_steps,
-                  S* __restrict__ surf_out /*[4][n]*/, int lpw)
+                  S* __restrict__ surf_out /*[4][n]*/, int lpw, int cfg_per_lane /*pid_cfg is [n][9][8]: one gain set per aircraft*/)
 {
     __shared__ double s_params[FD_MAX_TYPES * FD_NP];
     __shared__ float s_pid_cfg[FD_NPID * FD_NPC];
     __shared__ S s_consts[FD_NC];
     stage(s_params, params, n_types * FD_NP);
-    stage(s_pid_cfg, pid_cfg, FD_NPID * FD_NPC);
+    if (!cfg_per_lane) stage(s_pid_cfg, pid_cfg, FD_NPID * FD_NPC);
     for (int k = threadIdx.x; k < FD_NC; k += blockDim.x) s_consts[k] = S(consts[k]);
     __syncthreads();
     const LaneMap lm = lane_map(lpw, n);
@@ -233,7 +233,7 @@ agent_step_kernel(int level, S* __restrict__ xs, float* __restrict__ pid_state /
     PidState st[FD_NPID];
 #pragma unroll
     for (int k = 0; k < FD_NPID; ++k) {
-        cfg[k] = load_pid_cfg(s_pid_cfg, k);
+        cfg[k] = cfg_per_lane ? load_pid_cfg(pid_cfg + i * (FD_NPID * FD_NPC), k) : load_pid_cfg(s_pid_cfg, k);
         st[k] = PidState{ pid_state[(k * FD_NPS + FD_PS_INTEGRAL) * n + i], pid_state[(k * FD_NPS + FD_PS_ERR_PREV) * n + i],
                           pid_state[(k * FD_NPS + FD_PS_DFILT) * n + i] };
     }
@@ -804,8 +804,8 @@ int fdyn_pid_compute_batch(const float* cfg, int cfg_per_lane, float* state, con
     }
 #define FD_DEFINE_AGENT(NAME, S, T)                                                                          \
     int NAME(int level, S* x, float* pid_state, const uint8_t* type, const double* params, int n_types,      \
-             const float* pid_cfg, const double* consts, const S* cmd, int64_t n, double dt, int n_steps,    \
-             S* surf_out, void* stream)                                                                      \
+             const float* pid_cfg, int cfg_per_lane, const double* consts, const S* cmd, int64_t n, double dt, \
+             int n_steps, S* surf_out, void* stream)                                                         \
     {                                                                                                        \
         FD_CHECK_COMMON(n, n_types)                                                                          \
         if (level < FD_LEVEL_WAYPOINT || level > FD_LEVEL_RATE || n_steps < 0) return FDYN_ERR_BAD_SIZE;     \
@@ -814,7 +814,7 @@ int fdyn_pid_compute_batch(const float* cfg, int cfg_per_lane, float* state, con
         const int lpw = pick_lpw(n);                                                                         \
         hipLaunchKernelGGL((agent_step_kernel<S, T>), dim3(grid_lpw(n, lpw)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
                            level, x, pid_state, type, params, n_types, pid_cfg, consts, cmd, n, S(dt), n_steps, \
-                           surf_out, lpw);                                                                   \
+                           surf_out, lpw, cfg_per_lane);                                                     \
         return launch_status();                                                                              \
     }
 FD_DEFINE_AGENT(fdyn_agent_step_f64, double, double)

@@ -105,16 +105,18 @@ int fdyn_cascade_step_f32(float* x, float* pid_state, int32_t* wp_idx, const uin
  * command), throttle | HSA heading, speed, altitude, - | WAYPOINT north, east, altitude, speed (NaN = keep airspeed).
  * Replaces RateAgent / AttitudeAgent / HSAAgent / WaypointAgent.compute_action (controllers/rate_agent.py:65-124,
  * attitude_agent.py:86-154, hsa_agent.py:119-231, waypoint_agent.py:81-242) and the closed-loop helper the reference's tests
- * use (tests/test_control_integration.py:34-74).  pid_state / pid_cfg / consts as fdyn_cascade_step_*.                    */
+ * use (tests/test_control_integration.py:34-74).  pid_state / pid_cfg / consts as fdyn_cascade_step_*; cfg_per_lane != 0:
+ * pid_cfg is [n][FD_NPID][FD_NPC], one gain set PER AIRCRAFT -- a whole gain sweep (examples/tune_pids.py tries five sets one
+ * after the other) flies in one launch.                                                                                    */
 int fdyn_agent_step_f64(int level, double* x, float* pid_state, const uint8_t* type, const double* params, int n_types,
-                        const float* pid_cfg, const double* consts, const double* cmd, int64_t n, double dt, int n_steps,
-                        double* surf_out, void* stream);
+                        const float* pid_cfg, int cfg_per_lane, const double* consts, const double* cmd, int64_t n, double dt,
+                        int n_steps, double* surf_out, void* stream);
 int fdyn_agent_step_mixed(int level, double* x, float* pid_state, const uint8_t* type, const double* params, int n_types,
-                          const float* pid_cfg, const double* consts, const double* cmd, int64_t n, double dt, int n_steps,
-                          double* surf_out, void* stream);
+                          const float* pid_cfg, int cfg_per_lane, const double* consts, const double* cmd, int64_t n, double dt,
+                          int n_steps, double* surf_out, void* stream);
 int fdyn_agent_step_f32(int level, float* x, float* pid_state, const uint8_t* type, const double* params, int n_types,
-                        const float* pid_cfg, const double* consts, const float* cmd, int64_t n, double dt, int n_steps,
-                        float* surf_out, void* stream);
+                        const float* pid_cfg, int cfg_per_lane, const double* consts, const float* cmd, int64_t n, double dt,
+                        int n_steps, float* surf_out, void* stream);
 
 /* ---- rate-control env ------------------------------------------------------------------------------------------
  * x [FD_NX][n] ; e [FD_NE][n] (FD_E_*) ; ei [FD_NEI][n] int32 ; env_consts [FD_NEC] fp64 (FD_EC_*)

@@ -190,3 +190,33 @@ def test_cfg3_harness_through_single_aircraft_dropins():
     assert np.allclose([e[2] for e in events], want[:, 3], atol=1e-6)
     assert mission.is_active() and abs(mission.get_progress_percentage() - 40.0) < 1e-9
     assert abs(mission.get_total_mission_distance() - 1200.0) < 1e-9 and mission.get_summary()["waypoints_reached"] == 2
+
+
+def test_per_aircraft_gain_tables_match_oracle(oracle):
+    """cfg_per_lane: every aircraft flies its own PID gain set (a gain sweep in one launch); each lane against the oracle
+    run with that lane's table."""
+    rs = np.random.RandomState(4)
+    n, dt, steps = 48, 0.01, 150
+    base = cfgmod.pid_table(ControllerConfig())
+    tables = np.repeat(base[None], n, 0)
+    tables[:, :, L.FD_PC_KP] *= rs.uniform(0.5, 1.8, (n, L.FD_NPID)).astype(np.float32)
+    tables[:, :, L.FD_PC_KI] *= rs.uniform(0.5, 1.5, (n, L.FD_NPID)).astype(np.float32)
+    fleet = AgentFleet(n, "f64")
+    fleet.set_gain_tables(tables)
+    x0 = np.zeros((n, 12)); x0[:, 2] = -100.0; x0[:, 3] = 20.0
+    fleet.reset(x0)
+    cmd = np.array([0.3, 21.0, 110.0, 0.0])
+    fleet.run(L.FD_LEVEL_HSA, cmd, dt, steps)
+    got = fleet.state_numpy()
+    assert np.abs(got - got[0]).max() > 1e-3                                   # the lanes really flew different controllers
+    P, Cc = AircraftParams().to_block(), cfgmod.cascade_consts(ControllerConfig())
+    for i in range(0, n, 5):
+        x = x0[i].copy()
+        ps = np.zeros((L.FD_NPID, L.FD_NPS), np.float32)
+        pc = np.ascontiguousarray(tables[i])
+        surf = np.zeros(4)
+        for _ in range(steps):
+            oracle.lib.orc_hsa_agent(oracle.fp(pc), oracle.fp(ps), oracle.dp(Cc), oracle.dp(cmd[:3].copy()), oracle.dp(x),
+                                     oracle.dp(oracle.derived(x)), dt, oracle.dp(surf))
+            oracle.rk4_step(P, x, oracle.clip_controls(surf), dt)
+        assert rel_err(got[i], x, STATE_ANGLE_COLS).max() < 1e-6, i
