@@ -285,6 +285,9 @@ def cpu_baseline(args):
     unit = "aircraft-steps/s" if args.workload == "physics" else "env-steps/s"
     return {"value": n * reps / dt_all, "unit": unit, "cores": threads, "kind": "port",
             "single_core_value": n / dt_one,
+            # context, not measured in this run: the reference's own Python env step, timed by the survey in the build
+            # container (RateControlEnv.step, 214 env-steps/s on one core; the reference cannot travel)
+            "reference_python_single_core": 214.0 if unit == "env-steps/s" else None,
             "sample": f"oracle/flight_oracle.c (fp64, OpenMP), {n} envs x {reps} steps, {dt_all:.1f} s on {threads} threads"}
 
 
