@@ -361,8 +361,8 @@ def main():
         valu = tj.get(f"{args.workload}_{args.precision}_{args.batch}_valu")      # VALU-pipe occupancy from the same PMC runs
     out = {
         "metric": "env-steps/sec (whole node), rate-control task, batch 65536 per GPU" if args.workload.startswith("env")
-                  else f"{args.workload} aircraft-steps/sec",
-        "value": value, "unit": "env-steps/s" if args.workload.startswith("env") else "aircraft-steps/s",
+                  else f"{args.workload} {'env' if args.workload in ('rollout', 'train') else 'aircraft'}-steps/sec",
+        "value": value, "unit": "env-steps/s" if args.workload in ("env", "env_pid", "rollout", "train") else "aircraft-steps/s",
         "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": wall * 1e3 / K,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"f64": "f64", "mixed": "f32 compute / f64 state", "f32": "f32"}[args.precision],
