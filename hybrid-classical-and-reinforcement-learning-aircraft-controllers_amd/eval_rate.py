@@ -1,7 +1,8 @@
 """`python eval_rate.py --model <checkpoint.pt> [--compare-pid]` -- the reference's learned_controllers/eval_rate.py
 command line (:266-345: same flags) over the device path: every episode of an evaluation flies in parallel in one
 `GpuRateVecEnv`, metrics come from `fdyn_rate_metrics_*`.  `--model` takes a checkpoint written by `RecurrentPPO.save`
-(train_rate.py); the reference's SB3 .zip files need stable-baselines3 to unpickle and are not read here.
+(train_rate.py) or a Stable-Baselines3-layout .zip (weights read with weights_only=True; the pickled parts of such an
+archive are never decoded, sb3_zip.py).
 Extra flags: --seed, --precision, --pid-only (no model), --pid-true-dt (hand the PID the real env dt).
 """
 import argparse
@@ -13,10 +14,15 @@ from .policy import RateLSTMPolicy
 
 
 def load_policy(path: str, device="cuda", bf16: bool = True) -> RateLSTMPolicy:
-    ck = torch.load(path, map_location=device, weights_only=True)
-    sd = ck["policy"] if "policy" in ck else ck
-    use_lstm = any(k.startswith("lstm_actor") for k in sd)
-    pol = RateLSTMPolicy(use_lstm=use_lstm, compute_dtype=torch.bfloat16 if bf16 else None).to(device)
+    from .sb3_zip import is_sb3_zip, policy_kwargs_from_state_dict, read_sb3_zip
+    if is_sb3_zip(path):                        # Stable-Baselines3 archive layout: policy.pth read with weights_only=True
+        sd, _meta = read_sb3_zip(path, device)
+    else:
+        ck = torch.load(path, map_location=device, weights_only=True)
+        sd = ck["policy"] if "policy" in ck else ck
+    kw = policy_kwargs_from_state_dict(sd)      # network sizes from the tensor shapes
+    use_lstm = kw["use_lstm"]
+    pol = RateLSTMPolicy(compute_dtype=torch.bfloat16 if bf16 else None, **kw).to(device)
     pol.load_state_dict(sd)
     pol.eval()
     if use_lstm and bf16:

@@ -3,8 +3,10 @@
 `LearnedRateAgent(model_path, config)` keeps the reference's surface -- `compute_action(command, state, dt=None) ->
 ControlSurfaces`, `reset()`, `get_control_level()`, `using_fallback`, PID fallback -- so a policy trained here drops into
 the reference's cascade / GUI worker (gui/simulation_worker_learned.py:51-93) where its SB3 agent sits.  `model_path` is a
-checkpoint written by `RecurrentPPO.save` (train_rate.py); the reference's SB3 `.zip` files unpickle through
-stable-baselines3, which is absent here, so they are not read (parity unpinned for that file format).
+checkpoint written by `RecurrentPPO.save` (train_rate.py) or an archive in the Stable-Baselines3 `.zip` layout (the
+reference's own format, :87-118): its `policy.pth` is read with `weights_only=True` and mapped by name (sb3_zip.py);
+the pickled parts of such an archive are never decoded.  stable-baselines3 is absent here, so that file format is
+written and read from its published layout only (parity unpinned).
 `BatchedLearnedRateAgent` is the same mapping for a fleet: rate commands [N,3] + state block [12][N] -> actions [N,4].
 """
 from pathlib import Path

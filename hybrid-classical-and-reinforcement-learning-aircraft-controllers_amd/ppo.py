@@ -323,7 +323,19 @@ class RecurrentPPO:
         torch.save({"policy": self.policy.state_dict(), "optimizer": self.opt.state_dict(),
                     "num_timesteps": self.num_timesteps, "config": self.cfg.__dict__}, path)
 
+    def save_sb3_zip(self, path):
+        """Policy weights + plain hyper-parameters in the Stable-Baselines3 archive layout (what the reference's
+        `model.save(...)` writes, train_rate.py:353-355; see sb3_zip.py for what is and is not in the file)."""
+        from .sb3_zip import save_sb3_zip
+        return save_sb3_zip(path, self.policy, hyper=dict(self.cfg.__dict__), num_timesteps=self.num_timesteps)
+
     def load(self, path):
+        from .sb3_zip import is_sb3_zip, read_sb3_zip
+        if is_sb3_zip(path):                    # weights only: an SB3 archive's optimizer state is in SB3's parameter order
+            sd, meta = read_sb3_zip(path, self.device)
+            self.policy.load_state_dict(sd)
+            self.num_timesteps = int(meta["data"].get("num_timesteps", 0) or 0)
+            return self
         ck = torch.load(path, map_location=self.device, weights_only=True)
         self.policy.load_state_dict(ck["policy"]); self.opt.load_state_dict(ck["optimizer"])
         self.num_timesteps = ck["num_timesteps"]

@@ -107,6 +107,7 @@ def main(argv=None):
     if rank == 0:
         os.makedirs(config["paths"]["model_save_dir"], exist_ok=True)
         model.save(os.path.join(config["paths"]["model_save_dir"], "final_model.pt"))
+        model.save_sb3_zip(os.path.join(config["paths"]["model_save_dir"], "final_model"))   # train_rate.py:353-355 layout
         print("final evaluation:", {k: v for k, v in run_final_evaluation(model).items() if k.startswith("mean")})
     if world > 1:
         dist.destroy_process_group()

@@ -195,6 +195,18 @@ def test_train_rate_cli_end_to_end(tmp_path):
     train_rate.main(["--config", str(p), "--bf16", "--bc-pretrain", "1"])
     ck = torch.load(tmp_path / "ckpt" / "final_model.pt", weights_only=True)
     assert ck["num_timesteps"] == 3 * 512 * 8 and "policy" in ck
+    # the same weights in the reference's archive layout (train_rate.py:353-355 -> final_model.zip), readable by the Level-4 agent
+    from hcrl_amd import sb3_zip
+    from hcrl_amd.flight_types import ControllerConfig
+    from hcrl_amd.learned_rate_agent import LearnedRateAgent
+    zpath = tmp_path / "ckpt" / "final_model.zip"
+    assert sb3_zip.is_sb3_zip(zpath)
+    sd, meta = sb3_zip.read_sb3_zip(zpath)
+    assert meta["data"]["num_timesteps"] == 3 * 512 * 8 and meta["data"]["n_steps"] == 8
+    for k, v in ck["policy"].items():
+        assert torch.equal(sd[k], v.cpu().float()), k
+    agent = LearnedRateAgent(str(zpath), ControllerConfig(), fallback_to_pid=False)
+    assert agent.is_recurrent
 
 
 def test_callbacks_checkpoints_best_model_and_resume(tmp_path):
