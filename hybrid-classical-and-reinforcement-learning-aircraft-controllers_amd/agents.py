@@ -7,6 +7,7 @@ one launch with N = 1 and no physics (a drop-in, not the fast path).  `AgentFlee
 command row per aircraft, `compute_action` (surfaces only) or `run` (n_steps of agent -> set_controls -> RK4 in one launch),
 which is also how the reference's closed-loop tests drive these agents (tests/test_control_integration.py:34-74).
 """
+from abc import ABC, abstractmethod
 from typing import Optional
 
 import numpy as np
@@ -47,6 +48,132 @@ def command_row(command: ControlCommand) -> np.ndarray:
         w = command.waypoint
         return np.array([w.north, w.east, w.altitude, nan if w.speed is None else w.speed])
     raise ValueError(f"no PID agent for mode {command.mode}")
+
+
+# ---- observation / action spaces per control level: interfaces/agent.py:154-323 --------------------------------------
+_INF = float("inf")
+_OBS_SPACES = {          # :166-198
+    ControlMode.WAYPOINT: ((12,), "[pos(3), vel(3), att(3), wp_error(3)]"),
+    ControlMode.HSA: ((12,), "[pos(3), vel(3), att(3), target_HSA(3)]"),
+    ControlMode.RATE: ((10,), "[vel(3), att(3), rates(3), airspeed]"),
+    ControlMode.ATTITUDE: ((10,), "[vel(3), att(3), rates(3), airspeed]"),
+    ControlMode.SURFACE: ((14,), "[vel(3), att(3), rates(3), airspeed, aoa, sideslip, load]"),
+}
+_ACT_SPACES = {          # :214-246
+    ControlMode.WAYPOINT: ([-_INF, -_INF, -_INF, 0.0], [_INF, _INF, _INF, 100.0], "[N, E, D, speed]"),
+    ControlMode.HSA: ([0.0, 0.0, 0.0], [2 * np.pi, 100.0, 1000.0], "[heading(rad), speed(m/s), altitude(m)]"),
+    ControlMode.RATE: ([-1.0, -1.0, -1.0, 0.0], [1.0, 1.0, 1.0, 1.0], "[roll_rate, pitch_rate, yaw_rate, throttle]"),
+    ControlMode.ATTITUDE: ([-1.0, -1.0, -1.0, 0.0], [1.0, 1.0, 1.0, 1.0], "[roll_angle, pitch_angle, yaw_angle, throttle]"),
+    ControlMode.SURFACE: ([-1.0, -1.0, -1.0, 0.0], [1.0, 1.0, 1.0, 1.0], "[elevator, aileron, rudder, throttle]"),
+}
+
+
+def observation_space(mode: ControlMode) -> dict:
+    """interfaces/agent.py:154-200: {'shape', 'low', 'high', 'description'} of an agent commanded at `mode`."""
+    if mode not in _OBS_SPACES:
+        return {"shape": (0,), "low": 0, "high": 0}
+    shape, desc = _OBS_SPACES[mode]
+    return {"shape": shape, "low": -np.inf, "high": np.inf, "description": desc}
+
+
+def action_space(mode: ControlMode) -> dict:
+    """interfaces/agent.py:202-248."""
+    if mode not in _ACT_SPACES:
+        return {"shape": (0,), "low": 0, "high": 0}
+    lo, hi, desc = _ACT_SPACES[mode]
+    return {"shape": (len(lo),), "low": np.array(lo), "high": np.array(hi), "description": desc}
+
+
+def preprocess_observations(mode: ControlMode, x: torch.Tensor, airspeed: torch.Tensor, altitude: torch.Tensor) -> torch.Tensor:
+    """interfaces/agent.py:250-323 for a fleet: state block x [12][N] (+ airspeed / altitude [N]) -> observations [N, dim]
+    on the device of `x`.  The target-dependent columns of levels 1-2 are zeros and the aerodynamic-angle columns of level 5
+    are the reference's placeholders (0, 0, load factor 1): that is what the reference returns."""
+    n = x.shape[1]
+    if mode in (ControlMode.WAYPOINT, ControlMode.HSA):
+        return torch.cat([x[0:9].T, torch.zeros((n, 3), dtype=x.dtype, device=x.device)], 1)
+    if mode in (ControlMode.RATE, ControlMode.ATTITUDE):
+        return torch.cat([x[3:12].T, airspeed.to(x.dtype).reshape(n, 1)], 1)
+    if mode == ControlMode.SURFACE:
+        col = lambda v: torch.full((n, 1), v, dtype=x.dtype, device=x.device)      # noqa: E731
+        return torch.cat([x[3:12].T, airspeed.to(x.dtype).reshape(n, 1), col(0.0), col(0.0), col(1.0),
+                          altitude.to(x.dtype).reshape(n, 1)], 1)
+    raise ValueError(f"Unknown control level: {mode}")
+
+
+class RLAgentInterface(ABC):
+    """interfaces/agent.py:21-327: the contract of a learning agent at any control level (observation -> ControlCommand).
+    Abstract: `get_control_level`, `reset(initial_state)`, `get_action(observation)`; `update` / `save` / `load` default to
+    no-ops, `switch_control_level` raises, and the space / observation helpers follow the level."""
+
+    @abstractmethod
+    def get_control_level(self) -> ControlMode: ...
+
+    @abstractmethod
+    def reset(self, initial_state: AircraftState) -> None: ...
+
+    @abstractmethod
+    def get_action(self, observation: np.ndarray) -> ControlCommand: ...
+
+    def update(self, transition: dict) -> None:
+        pass
+
+    def save(self, path: str) -> None:
+        pass
+
+    def load(self, path: str) -> None:
+        pass
+
+    def switch_control_level(self, level: ControlMode) -> None:
+        raise NotImplementedError(f"{self.__class__.__name__} does not support level switching")       # :150-152
+
+    def get_observation_space(self) -> dict:
+        return observation_space(self.get_control_level())
+
+    def get_action_space(self) -> dict:
+        return action_space(self.get_control_level())
+
+    def preprocess_observation(self, state: AircraftState) -> np.ndarray:
+        x = torch.as_tensor(state.to_vector(), dtype=torch.float64).reshape(L.FD_NX, 1)
+        one = lambda v: torch.tensor([float(v)], dtype=torch.float64)                                   # noqa: E731
+        return preprocess_observations(self.get_control_level(), x, one(state.airspeed), one(state.altitude))[0].numpy()
+
+    def __repr__(self) -> str:
+        return f"{self.__class__.__name__}(level={self.get_control_level().name})"
+
+
+class SurfaceAgent:
+    """controllers/surface_agent.py:8-103, Level 5: surface commands pass straight through, saturated at the configured
+    limits.  No device work: the physics kernels apply the same clip when the surfaces are set (`Controls::set`)."""
+    _DEFAULTS = (("elevator", -1.0, 1.0), ("aileron", -1.0, 1.0), ("rudder", -1.0, 1.0), ("throttle", 0.0, 1.0))
+
+    def __init__(self, config: Optional[dict] = None):
+        self.config = config or {}
+        limits = self.config.get("surface_limits", {})
+        for name, lo, hi in self._DEFAULTS:
+            setattr(self, f"{name}_min", limits.get(f"{name}_min", lo))
+            setattr(self, f"{name}_max", limits.get(f"{name}_max", hi))
+
+    def get_control_level(self) -> ControlMode:
+        return ControlMode.SURFACE
+
+    def compute_action(self, command: ControlCommand, state: Optional[AircraftState] = None, dt: Optional[float] = None) -> ControlSurfaces:
+        assert command.mode == ControlMode.SURFACE, f"Surface agent expects SURFACE mode, got {command.mode}"
+        return ControlSurfaces(**{name: np.clip(getattr(command, name), getattr(self, f"{name}_min"), getattr(self, f"{name}_max"))
+                                  for name, _, _ in self._DEFAULTS})
+
+    def limits(self, device=None) -> torch.Tensor:
+        """[2][4] (min row, max row) in physics control order [elevator, aileron, rudder, throttle], for fleets:
+        `u.clamp(lim[0], lim[1])` on a `[N][4]` surface block is this agent for N aircraft."""
+        order = ("elevator", "aileron", "rudder", "throttle")
+        return torch.tensor([[getattr(self, f"{n}_min") for n in order], [getattr(self, f"{n}_max") for n in order]],
+                            dtype=torch.float64, device=device)
+
+    def reset(self):
+        pass
+
+    def __repr__(self) -> str:
+        return (f"SurfaceAgent(elevator=[{self.elevator_min}, {self.elevator_max}], aileron=[{self.aileron_min}, {self.aileron_max}], "
+                f"rudder=[{self.rudder_min}, {self.rudder_max}], throttle=[{self.throttle_min}, {self.throttle_max}])")
 
 
 class AgentFleet(BatchedSixDOF):

@@ -792,10 +792,78 @@ def gen_telemetry():
     print("   wrote telemetry_reference.json")
 
 
+def gen_spaces():
+    """RLAgentInterface's level-dependent helpers (interfaces/agent.py:154-323) for an agent at each of the five levels --
+    space definitions, preprocess_observation on a few flown states, the default switch_control_level error -- and the
+    Level-5 SurfaceAgent (controllers/surface_agent.py:8-103) on in-range / out-of-range commands."""
+    import json
+    from interfaces.agent import RLAgentInterface
+    from controllers.surface_agent import SurfaceAgent
+    print("agent observation / action spaces (reference RLAgentInterface) + SurfaceAgent")
+
+    class LevelAgent(RLAgentInterface):
+        def __init__(self, level):
+            self.level = level
+
+        def get_control_level(self):
+            return self.level
+
+        def reset(self, initial_state):
+            pass
+
+        def get_action(self, observation):
+            return ControlCommand(mode=self.level)
+
+    sim = Simplified6DOF()
+    sim.reset()
+    sim.set_controls(ControlSurfaces(elevator=-0.05, aileron=0.2, rudder=0.05, throttle=0.8))
+    states = []
+    for _ in range(3):
+        for _ in range(40):
+            sim.step(0.005)
+        states.append(sim.get_state())
+
+    def plain(v):
+        if isinstance(v, np.ndarray):
+            return v.tolist()
+        if isinstance(v, tuple):
+            return list(v)
+        return v
+    doc = {"states": [np.concatenate([state_vec_of(s), [s.airspeed, s.altitude]]).tolist() for s in states], "levels": {},
+           "surface_agent": []}
+    for mode in (ControlMode.WAYPOINT, ControlMode.HSA, ControlMode.ATTITUDE, ControlMode.RATE, ControlMode.SURFACE):
+        ag = LevelAgent(mode)
+        try:
+            ag.switch_control_level(ControlMode.HSA)
+            switch = None
+        except NotImplementedError as e:
+            switch = str(e)
+        doc["levels"][mode.name] = {
+            "observation_space": {k: plain(v) for k, v in ag.get_observation_space().items()},
+            "action_space": {k: plain(v) for k, v in ag.get_action_space().items()},
+            "observations": [ag.preprocess_observation(s).tolist() for s in states],
+            "repr": repr(ag), "switch_error": switch}
+    for cfg in (None, {"surface_limits": {"elevator_min": -0.5, "elevator_max": 0.4, "throttle_max": 0.9, "rudder_min": -0.2}}):
+        ag = SurfaceAgent(cfg)
+        cases = []
+        for cmd in ((0.3, -0.2, 0.1, 0.6), (-1.7, 1.4, -0.9, 1.3), (0.45, -1.0, 0.25, -0.2)):
+            out = ag.compute_action(ControlCommand(mode=ControlMode.SURFACE, elevator=cmd[0], aileron=cmd[1], rudder=cmd[2],
+                                                   throttle=cmd[3]), states[0])
+            cases.append({"command": list(cmd), "surfaces": [float(out.elevator), float(out.aileron), float(out.rudder), float(out.throttle)]})
+        doc["surface_agent"].append({"config": cfg, "repr": repr(ag), "level": ag.get_control_level().name, "cases": cases})
+    with open(os.path.join(OUT, "agent_spaces.json"), "w") as f:
+        json.dump(doc, f)
+    print("   wrote agent_spaces.json")
+
+
+def state_vec_of(st):
+    return np.concatenate([st.position, st.velocity, st.attitude, st.angular_rate])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["open", "stress", "pid", "agents", "cfg1", "cfg3", "samplers", "env", "eval", "sensor", "telemetry"]
+    which = sys.argv[1:] or ["open", "stress", "pid", "agents", "cfg1", "cfg3", "samplers", "env", "eval", "sensor", "telemetry", "spaces"]
     for w in which:
         {"open": gen_open_loop, "stress": gen_stress, "pid": gen_pid, "agents": gen_agents, "cfg1": gen_cfg1,
          "cfg3": gen_cfg3, "samplers": gen_samplers, "env": gen_env, "eval": gen_eval, "sensor": gen_sensor,
-         "telemetry": gen_telemetry}[w]()
+         "telemetry": gen_telemetry, "spaces": gen_spaces}[w]()
     print("done")

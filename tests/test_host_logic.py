@@ -101,3 +101,79 @@ def test_metrics_container_and_aggregation():
     b = RateControlMetrics()
     agg = aggregate_metrics([a, b])
     assert agg.total_reward == 8.0 and agg.success == 0.5 and agg.tracking_rmse == 6.5
+
+
+# ---- RLAgentInterface helpers + SurfaceAgent against the reference's outputs (tests/golden/agent_spaces.json) -------------
+def _spaces_fixture():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "agent_spaces.json")))
+
+
+def test_rl_agent_interface_spaces_and_observations_match_reference():
+    """interfaces/agent.py:154-323 (the reference's tests: tests/test_interfaces.py:43-150)."""
+    import torch
+    from hcrl_amd.agents import RLAgentInterface, preprocess_observations
+    from hcrl_amd.flight_types import AircraftState, ControlCommand, ControlMode
+
+    with pytest.raises(TypeError):
+        RLAgentInterface()                                   # abstract
+
+    class LevelAgent(RLAgentInterface):
+        def __init__(self, level):
+            self.level = level
+
+        def get_control_level(self):
+            return self.level
+
+        def reset(self, initial_state):
+            self.last_state = initial_state
+
+        def get_action(self, observation):
+            return ControlCommand(mode=self.level)
+
+    fx = _spaces_fixture()
+    rows = np.array(fx["states"])
+    states = [AircraftState(position=r[0:3], velocity=r[3:6], attitude=r[6:9], angular_rate=r[9:12], airspeed=r[12], altitude=r[13])
+              for r in rows]
+    for name, want in fx["levels"].items():
+        ag = LevelAgent(ControlMode[name])
+        for getter, key in ((ag.get_observation_space, "observation_space"), (ag.get_action_space, "action_space")):
+            got = getter()
+            assert set(got) == set(want[key]), (name, key)
+            for k, v in want[key].items():
+                g = got[k]
+                assert (tuple(g) == tuple(v)) if k == "shape" else np.array_equal(np.asarray(g, dtype=object if isinstance(g, str) else None), np.asarray(v, dtype=object if isinstance(v, str) else None)), (name, key, k)
+        for st, obs in zip(states, want["observations"]):
+            assert np.array_equal(ag.preprocess_observation(st), np.array(obs)), name
+        # the fleet form: all states at once
+        batch = preprocess_observations(ControlMode[name], torch.as_tensor(rows[:, :12].T.copy()), torch.as_tensor(rows[:, 12]),
+                                        torch.as_tensor(rows[:, 13]))
+        assert np.array_equal(batch.numpy(), np.array(want["observations"])), name
+        assert repr(ag) == want["repr"]
+        with pytest.raises(NotImplementedError, match="does not support level switching") as e:
+            ag.switch_control_level(ControlMode.HSA)
+        assert str(e.value) == want["switch_error"]
+        assert ag.update({"reward": 1.0}) is None and ag.save("x") is None and ag.load("x") is None
+        ag.reset(states[0])
+        assert ag.last_state is states[0] and ag.get_action(np.zeros(10)).mode == ControlMode[name]
+
+
+def test_surface_agent_matches_reference():
+    """controllers/surface_agent.py:8-103."""
+    import torch
+    from hcrl_amd.agents import SurfaceAgent
+    from hcrl_amd.flight_types import ControlCommand, ControlMode
+    for want in _spaces_fixture()["surface_agent"]:
+        ag = SurfaceAgent(want["config"])
+        assert repr(ag) == want["repr"] and ag.get_control_level().name == want["level"]
+        lim = ag.limits()
+        for case in want["cases"]:
+            e, a, r, t = case["command"]
+            out = ag.compute_action(ControlCommand(mode=ControlMode.SURFACE, elevator=e, aileron=a, rudder=r, throttle=t), None)
+            assert [float(out.elevator), float(out.aileron), float(out.rudder), float(out.throttle)] == case["surfaces"]
+            fleet = torch.tensor([case["command"]], dtype=torch.float64)
+            assert torch.minimum(torch.maximum(fleet, lim[0]), lim[1])[0].tolist() == case["surfaces"]
+        with pytest.raises(AssertionError, match="expects SURFACE mode"):
+            ag.compute_action(ControlCommand(mode=ControlMode.RATE, roll_rate=0.0, pitch_rate=0.0, yaw_rate=0.0), None)
+        ag.reset()
