@@ -51,12 +51,13 @@ class RateControlEnv:
 
     def __init__(self, difficulty: str = "medium", episode_length: float = 10.0, dt: float = 0.02,
                  command_type: str = "step", render_mode: Optional[str] = None, rng_seed: Optional[int] = None,
-                 precision: str = "f64"):
+                 precision: str = "f64", residual_scale: float = 0.0):
         self.difficulty, self.episode_length, self.dt, self.command_type = difficulty, episode_length, dt, command_type
         self.render_mode = render_mode
         self._streams = EpisodeStreams(difficulty, command_type, rng_seed)
+        # residual_scale > 0: `step` takes residuals and the fused rate PID supplies the baseline (ResidualRateControlEnv below)
         self._vec = GpuRateVecEnv(1, difficulty, episode_length, dt, command_type, seed=rng_seed, precision=precision,
-                                  sampling="device")
+                                  sampling="device", residual_scale=residual_scale)
         self._vec.pool = torch.zeros((1, 1, L.FD_NR), dtype=torch.float64, device=self._vec.device)
         self._vec.pool_depth = 1
         self.sim = _SimView(self)
@@ -107,3 +108,67 @@ class RateControlEnv:
 
     def close(self):
         pass
+
+
+class ResidualRateControlEnv:
+    """learned_controllers/envs/residual_rate_env.py:17-182: the action is a correction ADDED to the rate PID's output
+    (`clip(PID + residual_scale * action)`), with a small bonus for small corrections.
+
+    One fused launch per step: the kernel evaluates the rate PID (throttle command 0.6, PID dt = env dt, as :115-125),
+    adds the scaled residual in float32, clips, steps and adds the bonus (`rate_env_step_kernel`, residual mode).  The
+    `info` keys of :147-149 come from that launch (`combined_action` = the action the kernel applied) and from a
+    `RateAgent` drop-in fed the same command and state just before it (`pid_action`, what the reference's own
+    `self.pid_agent` returns; its fp32 PID state evolves bit-identically to the fused one)."""
+    metadata = {"render_modes": ["human"], "render_fps": 50}
+
+    def __init__(self, difficulty: str = "medium", episode_length: float = 10.0, dt: float = 0.02, command_type: str = "step",
+                 render_mode: Optional[str] = None, rng_seed: Optional[int] = None, residual_scale: float = 0.3,
+                 precision: str = "f64"):
+        from .agents import RateAgent
+        from .flight_types import ControllerConfig
+        if not residual_scale > 0.0:
+            raise ValueError("residual_scale must be > 0 (use RateControlEnv for direct surface actions)")
+        self.residual_scale = residual_scale
+        self.base_env = RateControlEnv(difficulty=difficulty, episode_length=episode_length, dt=dt, command_type=command_type,
+                                       render_mode=render_mode, rng_seed=rng_seed, precision=precision,
+                                       residual_scale=residual_scale)
+        self.pid_config = ControllerConfig()
+        self.pid_agent = RateAgent(self.pid_config)
+        self.observation_space = self.base_env.observation_space
+        self.action_space = Box([-1.0, -1.0, -1.0, -1.0], [1.0, 1.0, 1.0, 1.0], np.float32)
+        self.last_pid_action = np.zeros(4)
+
+    def reset(self, seed: Optional[int] = None, options: Optional[Dict[str, Any]] = None) -> Tuple[np.ndarray, Dict[str, Any]]:
+        obs, info = self.base_env.reset(seed=seed, options=options)
+        self.pid_agent.reset()
+        self.last_pid_action = np.zeros(4)
+        info["pid_action"] = self.last_pid_action.copy()
+        return obs, info
+
+    def step(self, residual_action) -> Tuple[np.ndarray, float, bool, bool, Dict[str, Any]]:
+        from .flight_types import ControlCommand, ControlMode
+        residual_action = np.asarray(residual_action, dtype=np.float32)
+        p_cmd, q_cmd, r_cmd = self.base_env.rate_command
+        command = ControlCommand(mode=ControlMode.RATE, roll_rate=p_cmd, pitch_rate=q_cmd, yaw_rate=r_cmd, throttle=0.6)
+        surfaces = self.pid_agent.compute_action(command, self.base_env.sim.get_state(), dt=self.base_env.dt)
+        pid_action = np.array([surfaces.aileron, surfaces.elevator, surfaces.rudder, surfaces.throttle], dtype=np.float32)
+        self.last_pid_action = pid_action.copy()
+        obs, reward, terminated, truncated, info = self.base_env.step(residual_action)
+        info["pid_action"] = pid_action
+        info["residual_action"] = residual_action * np.float32(self.residual_scale)
+        info["combined_action"] = self.base_env._vec.actions_taken[0].cpu().numpy().copy()
+        return obs, reward, terminated, truncated, info
+
+    @property
+    def sim(self):
+        return self.base_env.sim
+
+    @property
+    def rate_command(self):
+        return self.base_env.rate_command
+
+    def render(self):
+        return self.base_env.render()
+
+    def close(self):
+        self.base_env.close()

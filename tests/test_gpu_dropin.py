@@ -184,3 +184,33 @@ def test_reference_simulation_checks_as_one_fleet(precision):
     for _ in range(20):                                           # coarse steps (:211-223)
         f.step(0.1)
     assert np.isfinite(f.state_numpy()).all()
+
+
+def test_residual_rate_control_env_dropin_vs_reference_fixture():
+    """ResidualRateControlEnv (learned_controllers/envs/residual_rate_env.py:17-182) as a single-env drop-in: spaces,
+    reset/step signature, info keys, and a whole episode against the reference-composed fixture -- observations, rewards
+    (with the small-correction bonus), the PID baseline and the combined action."""
+    from hcrl_amd.gym_env import ResidualRateControlEnv, RateControlEnv
+    g = load_golden("env_residual_medium_step_seed17.npz")
+    env = ResidualRateControlEnv(difficulty="medium", command_type="step", rng_seed=17, residual_scale=float(g["scale"]))
+    assert env.residual_scale == 0.3 and isinstance(env.base_env, RateControlEnv)
+    assert env.observation_space is env.base_env.observation_space and env.observation_space.shape == (18,)
+    assert np.array_equal(env.action_space.low, [-1.0] * 4) and np.array_equal(env.action_space.high, [1.0] * 4)
+    obs, info = env.reset(seed=17)
+    assert np.array_equal(info["pid_action"], np.zeros(4)) and rel_err(obs, g["obs"][0]).max() < 1e-6
+    n = len(g["rewards"])
+    for k in range(n):
+        cmd_before = env.rate_command.copy()
+        obs, reward, term, trunc, info = env.step(g["residual"][k])
+        assert np.abs(info["pid_action"] - g["pid_actions"][k]).max() < 2e-6, k          # fp32 PID output, one ulp
+        assert np.abs(info["combined_action"] - g["combined"][k]).max() < 2e-6, k
+        assert np.array_equal(info["residual_action"], g["residual"][k] * np.float32(0.3))
+        assert abs(reward - g["rewards"][k]) < 1e-6 and (term, trunc) == tuple(bool(f) for f in g["flags"][k]), k
+        assert rel_err(obs, g["obs"][k + 1]).max() < 1e-6, k
+        assert np.array_equal(env.last_pid_action, info["pid_action"]) and cmd_before.shape == (3,)
+    assert term or trunc
+    assert {"time", "step", "rate_command", "rate_error", "airspeed", "altitude", "is_settled"} <= set(info)
+    assert env.sim.get_state().altitude == pytest.approx(info["altitude"]) and env.render() is None
+    env.close()
+    with pytest.raises(ValueError):
+        ResidualRateControlEnv(residual_scale=0.0)
