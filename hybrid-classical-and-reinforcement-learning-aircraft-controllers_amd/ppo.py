@@ -105,6 +105,31 @@ def compute_gae(rewards, values, episode_starts, last_values, last_dones, gamma,
     return adv, adv + values
 
 
+@torch.no_grad()
+def episode_stats_from_rollout(rew, starts, final_start, run_ret, run_len):
+    """Monitor-style bookkeeping over one rollout without a per-step host loop: `rew` [T, N] per-step rewards, `starts`
+    [T, N] episode-start flags of the observations (starts[t] = done after step t-1), `final_start` [N] = done after the
+    last step, `run_ret` / `run_len` [N] the return / length each env had accumulated before the rollout.
+    -> (sum of returns, sum of lengths, count) of the episodes that ended inside the rollout as one [3] tensor, plus the
+    new carries.  (What SB3's Monitor wrapper + `ep_info_buffer` feed `rollout/ep_rew_mean`, `rollout/ep_len_mean`.)"""
+    T, N = rew.shape
+    done = torch.cat([starts[1:], final_start[None]], 0) > 0
+    cs = rew.double().cumsum(0)
+    t = torch.arange(T, device=rew.device)[:, None].expand(T, N)
+    last = torch.where(done, t, torch.full_like(t, -1)).cummax(0).values          # last step <= t that ended an episode
+    prev = torch.cat([torch.full((1, N), -1, dtype=last.dtype, device=rew.device), last[:-1]], 0)   # ... strictly before t
+    has = prev >= 0
+    zero = torch.zeros((), dtype=cs.dtype, device=rew.device)
+    ep_ret = cs - torch.where(has, cs.gather(0, prev.clamp(min=0)), zero) + torch.where(has, zero, run_ret.double()[None])
+    ep_len = (t - prev).double() + torch.where(has, zero, run_len.double()[None])
+    sums = torch.stack([(ep_ret * done).sum(), (ep_len * done).sum(), done.sum().double()])
+    fl = last[-1]
+    ended = fl >= 0
+    new_ret = torch.where(ended, cs[-1] - cs.gather(0, fl.clamp(min=0)[None])[0], cs[-1] + run_ret.double())
+    new_len = torch.where(ended, (T - 1 - fl).double(), T + run_len.double())
+    return sums, new_ret, new_len
+
+
 class RecurrentPPO:
     def __init__(self, env, policy: Optional[RateLSTMPolicy] = None, config: Optional[PPOConfig] = None, seed: int = 0,
                  use_graph: bool = True, use_update_graph: Optional[bool] = None):
@@ -130,6 +155,12 @@ class RecurrentPPO:
         self.num_timesteps = 0
         self.ep_returns, self.ep_lengths = [], []
         self.last_stats = {}
+        # Monitor-style episode statistics (rollout/ep_rew_mean, ep_len_mean): off unless a logger asks -- learn() turns
+        # it on when it is given a callback; costs a dozen small launches and one host read per iteration
+        self.track_episode_stats = False
+        self._run_ret = torch.zeros(N, dtype=torch.float64, device=self.device)
+        self._run_len = torch.zeros(N, dtype=torch.float64, device=self.device)
+        self._ep_stats = {}
 
     def _alloc_states(self, n):
         """Fixed recurrent-state buffers: h in the policy's compute dtype (what the MFMA cell emits), c in fp32."""
@@ -299,12 +330,21 @@ class RecurrentPPO:
         n = max(stats.pop("n"), 1)
         self.last_stats = {k: float(v.detach() if torch.is_tensor(v) else v) / n for k, v in stats.items()}
         self.last_stats["mean_reward_per_step"] = float(self.buf_rew.mean()) / cfg.reward_scale
+        if self.track_episode_stats:
+            sums, self._run_ret, self._run_len = episode_stats_from_rollout(self.buf_rew / cfg.reward_scale, self.buf_start,
+                                                                            self.episode_start, self._run_ret, self._run_len)
+            ret_sum, len_sum, count = sums.tolist()
+            if count > 0:                                 # no episode ended in this rollout: keep the previous means
+                self._ep_stats = {"ep_rew_mean": ret_sum / count, "ep_len_mean": len_sum / count}
+            self.last_stats.update(self._ep_stats, episodes=count)
         return self.last_stats
 
     def learn(self, total_timesteps: int, log_interval: int = 1, callback=None):
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         target = self.num_timesteps + total_timesteps // world
         it, t0 = 0, time.time()
+        if callback is not None:
+            self.track_episode_stats = True
         while self.num_timesteps < target:
             self.collect_rollout()
             st = self.update()

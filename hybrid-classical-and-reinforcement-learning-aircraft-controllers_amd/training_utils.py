@@ -2,6 +2,7 @@
 learned_controllers/utils/pid_demonstrations.py:13-110), over the device-resident env.
 """
 import os
+import time
 from typing import Optional, Tuple
 
 import numpy as np
@@ -188,8 +189,9 @@ class EvalCallback:
     the best mean reward so far kept as `<best_model_save_path>/best_model.pt`."""
 
     def __init__(self, difficulty: str, best_model_save_path: str, log_path: str, eval_freq: int, n_eval_episodes: int = 10,
-                 deterministic: bool = True, residual_scale: float = 0.0):
+                 deterministic: bool = True, residual_scale: float = 0.0, writer=None):
         self.difficulty, self.best_dir, self.log_dir = difficulty, best_model_save_path, log_path
+        self.writer = writer                               # ProgressLogger: eval/mean_reward, eval/mean_ep_length
         self.residual_scale = residual_scale
         self.eval_freq, self.n_eval_episodes, self.deterministic = max(int(eval_freq), 1), n_eval_episodes, deterministic
         self._last, self.best_mean_reward = 0, -float("inf")
@@ -206,6 +208,9 @@ class EvalCallback:
         os.makedirs(self.log_dir, exist_ok=True)
         np.savez(os.path.join(self.log_dir, "evaluations.npz"), timesteps=np.array(self.timesteps),
                  results=np.array(self.results), ep_lengths=np.array(self.ep_lengths))
+        if self.writer is not None:
+            self.writer.scalars({"eval/mean_reward": float(ev["mean_reward"]), "eval/mean_ep_length": float(np.mean(ev["lengths"]))},
+                                int(model.num_timesteps))
         if ev["mean_reward"] > self.best_mean_reward:
             self.best_mean_reward = ev["mean_reward"]
             os.makedirs(self.best_dir, exist_ok=True)
@@ -213,18 +218,45 @@ class EvalCallback:
 
 
 class ProgressLogger:
-    """Per-iteration scalars as JSON lines in `<tensorboard_log>/progress.jsonl` (the reference hands `tensorboard_log` to SB3,
-    train_rate.py:144; TensorBoard is not in this image, the scalars are the same: losses, KL, clip fraction, reward)."""
+    """Per-iteration scalars, twice: JSON lines in `<tensorboard_log>/progress.jsonl`, and a TensorBoard event file
+    `<tensorboard_log>/events.out.tfevents.*` under SB3's tag names -- the reference hands `tensorboard_log` to SB3
+    (train_rate.py:144) and reads those files back in visualize/learning_curves.py:35-121.  TensorBoard is not in this
+    image: tfevents.py writes the format directly."""
+    TAGS = {"ep_rew_mean": "rollout/ep_rew_mean", "ep_len_mean": "rollout/ep_len_mean", "value_loss": "train/value_loss",
+            "policy_loss": "train/policy_gradient_loss", "approx_kl": "train/approx_kl", "clip_frac": "train/clip_fraction",
+            "grad_norm": "train/grad_norm", "mean_reward_per_step": "rollout/mean_reward_per_step"}
 
-    def __init__(self, log_dir: str):
+    def __init__(self, log_dir: str, tensorboard: bool = True):
         os.makedirs(log_dir, exist_ok=True)
         self.path = os.path.join(log_dir, "progress.jsonl")
         self._f = open(self.path, "a")
+        self.events = None
+        if tensorboard:
+            from .tfevents import EventFileWriter
+            self.events = EventFileWriter(log_dir)
+        self._t0, self._steps0 = time.time(), None
+
+    def scalars(self, values: dict, step: int):
+        """Extra scalars under their full tag names (EvalCallback: eval/mean_reward, eval/mean_ep_length)."""
+        if self.events is not None:
+            self.events.add_scalars(values, step)
+            self.events.flush()
 
     def __call__(self, model, stats):
         import json
-        self._f.write(json.dumps({"timesteps": int(model.num_timesteps), **{k: float(v) for k, v in stats.items()}}) + "\n")
+        step = int(model.num_timesteps)
+        self._f.write(json.dumps({"timesteps": step, **{k: float(v) for k, v in stats.items()}}) + "\n")
         self._f.flush()
+        if self.events is None:
+            return
+        if self._steps0 is None:
+            self._steps0 = step - model.cfg.n_steps * model.env.num_envs
+        tb = {tag: float(stats[k]) for k, tag in self.TAGS.items() if k in stats}
+        tb["train/entropy_loss"] = -float(model.policy.entropy().detach())
+        tb["train/std"] = float(model.policy.log_std.detach().exp().mean())
+        tb["train/learning_rate"] = float(model.opt.param_groups[0]["lr"])
+        tb["time/fps"] = (step - self._steps0) / max(time.time() - self._t0, 1e-9)
+        self.scalars(tb, step)
 
 
 class CallbackList:
@@ -242,11 +274,12 @@ def create_callbacks(config: dict, eval_env=None, flight_logger=None) -> Callbac
     TensorBoard flight-logging callback needs its tensorboard plugin, which is outside the hot path.)"""
     paths, tr, ev = config["paths"], config["training"], config.get("evaluation", {})
     difficulty = config.get("environment", {}).get("difficulty", "medium")
+    progress = ProgressLogger(paths["tensorboard_log"])
     return CallbackList([
         EvalCallback(difficulty, paths["best_model_path"], paths["best_model_path"], tr["eval_freq"],
-                     ev.get("n_eval_episodes", 10), ev.get("deterministic", True)),
+                     ev.get("n_eval_episodes", 10), ev.get("deterministic", True), writer=progress),
         CheckpointCallback(tr["save_freq"], paths["model_save_dir"], "rate_controller"),
-        ProgressLogger(paths["tensorboard_log"])])
+        progress])
 
 
 def find_best_checkpoint(log_path: str):

@@ -233,6 +233,16 @@ def test_callbacks_checkpoints_best_model_and_resume(tmp_path):
     import json
     rows = [json.loads(l) for l in open(tmp_path / "tb" / "progress.jsonl")]
     assert [r["timesteps"] for r in rows] == [2048 * k for k in range(1, 7)] and "approx_kl" in rows[0]
+    # the same scalars as a TensorBoard event file under SB3's tags (what visualize/learning_curves.py:35-121 loads)
+    from hcrl_amd import tfevents
+    tb = tfevents.load_scalars(str(tmp_path / "tb"))
+    for tag in ("train/value_loss", "train/policy_gradient_loss", "train/approx_kl", "train/clip_fraction", "train/entropy_loss",
+                "train/std", "train/learning_rate", "time/fps"):
+        assert [r[0] for r in tb[tag]] == [2048 * k for k in range(1, 7)], tag
+    assert [r[1] for r in tb["train/approx_kl"]] == pytest.approx([r["approx_kl"] for r in rows], rel=1e-6, abs=1e-9)
+    assert [r[0] for r in tb["eval/mean_reward"]] == [4096, 8192, 12288]
+    assert [r[1] for r in tb["eval/mean_reward"]] == pytest.approx(ev["results"].mean(1), rel=1e-6)
+    assert all("episodes" in r for r in rows)                     # Monitor-style episode bookkeeping ran every iteration
     best = find_best_checkpoint(str(tmp_path / "best"))
     assert best[0] in (4096, 8192, 12288) and abs(best[1] - ev["results"].mean(1).max()) < 1e-6
     train_rate.main(["--config", str(p), "--resume", str(tmp_path / "ckpt" / "rate_controller_6144_steps.pt")])
@@ -464,3 +474,33 @@ seed: 7
     train_rate.main(["--config", str(p)])
     ck = torch.load(tmp_path / "m" / "final_model.pt", weights_only=True)
     assert ck["num_timesteps"] == 2 * 8192 and not any(k.startswith("lstm_actor") for k in ck["policy"])
+
+
+def test_episode_statistics_of_training_rollouts():
+    """rollout/ep_rew_mean, ep_len_mean: with 0.4 s episodes every env finishes episodes inside each rollout; lengths must be
+    the truncation length and the mean return must equal the return computed from the buffers episode by episode."""
+    from hcrl_amd.policy import RateLSTMPolicy
+    from hcrl_amd.ppo import PPOConfig, RecurrentPPO
+    from hcrl_amd.rate_env import GpuRateVecEnv
+    env = GpuRateVecEnv(64, "easy", 0.4, 0.02, "step", seed=3, precision="mixed", sampling="device")      # 20-step episodes
+    ppo = RecurrentPPO(env, RateLSTMPolicy(compute_dtype=torch.bfloat16), PPOConfig(n_steps=32, n_epochs=1, n_minibatches=1), seed=0)
+    ppo.track_episode_stats = True
+    seen = []
+    for _ in range(3):
+        ppo.collect_rollout()
+        rew = (ppo.buf_rew / ppo.cfg.reward_scale).double().cpu().numpy()
+        starts = ppo.buf_start.cpu().numpy()
+        final = ppo.episode_start.cpu().numpy()
+        st = ppo.update()
+        seen.append((st["ep_rew_mean"], st["ep_len_mean"], st["episodes"], rew, starts, final))
+    run_ret, run_len = np.zeros(64), np.zeros(64)
+    for mean_ret, mean_len, count, rew, starts, final in seen:
+        rets, lens = [], []
+        for t in range(rew.shape[0]):
+            done = starts[t + 1] if t + 1 < rew.shape[0] else final
+            run_ret += rew[t]; run_len += 1
+            for n in np.nonzero(done > 0)[0]:
+                rets.append(run_ret[n]); lens.append(run_len[n]); run_ret[n] = 0.0; run_len[n] = 0
+        assert count == len(rets) and count >= 64
+        assert mean_ret == pytest.approx(np.mean(rets), rel=1e-9) and mean_len == pytest.approx(np.mean(lens))
+        assert max(lens) <= 20                                       # truncation at episode_length / dt steps
