@@ -249,12 +249,16 @@ class ProgressLogger:
         self._f.flush()
         if self.events is None:
             return
-        if self._steps0 is None:
-            self._steps0 = step - model.cfg.n_steps * model.env.num_envs
+        if self._steps0 is None:                           # timesteps at the start of the first logged iteration
+            cfg, env = getattr(model, "cfg", None), getattr(model, "env", None)
+            self._steps0 = step - cfg.n_steps * env.num_envs if cfg is not None and env is not None else 0
         tb = {tag: float(stats[k]) for k, tag in self.TAGS.items() if k in stats}
-        tb["train/entropy_loss"] = -float(model.policy.entropy().detach())
-        tb["train/std"] = float(model.policy.log_std.detach().exp().mean())
-        tb["train/learning_rate"] = float(model.opt.param_groups[0]["lr"])
+        policy, opt = getattr(model, "policy", None), getattr(model, "opt", None)
+        if policy is not None:
+            tb["train/entropy_loss"] = -float(policy.entropy().detach())
+            tb["train/std"] = float(policy.log_std.detach().exp().mean())
+        if opt is not None:
+            tb["train/learning_rate"] = float(opt.param_groups[0]["lr"])
         tb["time/fps"] = (step - self._steps0) / max(time.time() - self._t0, 1e-9)
         self.scalars(tb, step)
 
