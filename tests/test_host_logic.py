@@ -177,3 +177,34 @@ def test_surface_agent_matches_reference():
         with pytest.raises(AssertionError, match="expects SURFACE mode"):
             ag.compute_action(ControlCommand(mode=ControlMode.RATE, roll_rate=0.0, pitch_rate=0.0, yaw_rate=0.0), None)
         ag.reset()
+
+
+def test_recover_training_picks_copies_and_verifies(tmp_path, capsys):
+    """learned_controllers/recover_training.py:18-152 over this trainer's files."""
+    import torch
+    from hcrl_amd import recover_training, sb3_zip
+    from hcrl_amd.policy import RateLSTMPolicy
+    ck, ev = tmp_path / "ckpt", tmp_path / "best"
+    ck.mkdir(); ev.mkdir()
+    pol = RateLSTMPolicy(use_lstm=False)
+    for steps in (2000, 4000, 6000):
+        torch.save({"policy": pol.state_dict(), "num_timesteps": steps}, ck / f"rate_controller_{steps}_steps.pt")
+    (ck / "unrelated.pt").write_bytes(b"x")
+    np.savez(ev / "evaluations.npz", timesteps=np.array([1500, 4100, 5900]), results=np.array([[1.0, 2.0], [9.0, 7.0], [3.0, 4.0]]),
+             ep_lengths=np.zeros((3, 2)))
+    assert [s for s, _ in recover_training.list_checkpoints(str(ck))] == [2000, 4000, 6000]
+    out = tmp_path / "rec" / "recovered.pt"
+    step = recover_training.main(["--output", str(out), "--checkpoint-dir", str(ck), "--eval-dir", str(ev)])
+    assert step == 4000 and torch.load(out, weights_only=True)["num_timesteps"] == 4000
+    text = capsys.readouterr().out
+    assert "Best evaluation: step 4100 (reward: 8.00)" in text and "RECOVERY COMPLETE!" in text and "--resume" in text
+    assert recover_training.main(["--checkpoint-step", "6000", "--output", str(out), "--checkpoint-dir", str(ck)]) == 6000
+    with pytest.raises(SystemExit):                                       # a step that was never saved: lists what exists
+        recover_training.main(["--checkpoint-step", "123", "--output", str(out), "--checkpoint-dir", str(ck)])
+    assert "rate_controller_2000_steps.pt" in capsys.readouterr().out
+    # no evaluation file: earliest checkpoint; an archive in SB3's layout verifies too
+    sb3_zip.save_sb3_zip(ck / "rate_controller_1000_steps.zip", pol)
+    assert recover_training.main(["--output", str(tmp_path / "r.zip"), "--checkpoint-dir", str(ck), "--eval-dir", str(tmp_path / "none")]) == 1000
+    (ck / "rate_controller_500_steps.pt").write_bytes(b"not a checkpoint")
+    with pytest.raises(SystemExit):                                       # copy succeeds, verification fails
+        recover_training.main(["--checkpoint-step", "500", "--output", str(out), "--checkpoint-dir", str(ck)])
