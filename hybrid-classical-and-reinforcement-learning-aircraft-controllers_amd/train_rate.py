@@ -32,6 +32,9 @@ def main(argv=None):
                     help="override a config entry, e.g. --set ppo.learning_rate=1e-3 --set training.n_envs=4096")
     ap.add_argument("--bf16", action="store_true", help="run the policy GEMMs in bf16 (fp32 accumulate)")
     ap.add_argument("--resume", type=str, default=None, help="checkpoint (RecurrentPPO.save) to continue from")
+    ap.add_argument("--skip-demos", action="store_true",
+                    help="train_overnight.py:91: reuse the demonstrations at `demonstrations.save_path` instead of flying new ones")
+    ap.add_argument("--skip-bc", action="store_true", help="train_overnight.py:92: no behaviour cloning even if the config asks for it")
     ap.add_argument("--callbacks", action="store_true",
                     help="periodic evaluation (best model, evaluations.npz) and checkpoints per the config's eval_freq / save_freq")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -80,12 +83,25 @@ def main(argv=None):
     callback = create_callbacks(config) if (args.callbacks and rank == 0) else None
 
     imit = config.get("imitation")                          # train_overnight-style files carry their own imitation settings
-    if (args.bc_pretrain or (imit and not args.resume)) and rank == 0:
-        obs, acts = collect_pid_demonstrations(n_episodes=imit["n_episodes"] if (imit and not args.bc_pretrain) else 2048,
-                                               difficulty=imit["difficulty"] if (imit and not args.bc_pretrain) else "medium", seed=seed)
+    if (args.bc_pretrain or (imit and not args.resume and not args.skip_bc)) and rank == 0:
+        from_cfg = bool(imit) and not args.bc_pretrain
+        demo_path = imit.get("save_path") if from_cfg else None
+        if demo_path and not demo_path.endswith(".npz"):     # the reference pickles to `*.pkl`; this package writes data-only .npz
+            demo_path += ".npz"
+        if from_cfg and args.skip_demos and demo_path and os.path.exists(demo_path):       # train_overnight.py:120-123
+            from .training_utils import load_demonstrations
+            print(f"Loading existing demos from {demo_path}")
+            obs, acts = load_demonstrations(demo_path)
+        else:
+            obs, acts = collect_pid_demonstrations(n_episodes=imit["n_episodes"] if from_cfg else 2048,
+                                                   difficulty=imit["difficulty"] if from_cfg else "medium", seed=seed,
+                                                   save_path=demo_path)
         kw = dict(epochs=args.bc_pretrain) if args.bc_pretrain else dict(epochs=imit["epochs"], batch_size=imit["batch_size"],
                                                                          lr=imit["learning_rate"])
         print("BC losses:", behavior_cloning_pretrain(model, obs, acts, **kw))
+        if from_cfg:                                        # train_overnight.py:181-183
+            os.makedirs(config["paths"]["model_save_dir"], exist_ok=True)
+            model.save(os.path.join(config["paths"]["model_save_dir"], "bc_pretrained.pt"))
     if world > 1:
         from .ppo import broadcast_parameters
         broadcast_parameters(model.policy)

@@ -65,6 +65,7 @@ def normalize_config(config: dict) -> dict:
     if c.get("approach", {}).get("use_imitation"):
         demo, bc = c.get("demonstrations", {}), c.get("behavior_cloning", {})
         c["imitation"] = {"n_episodes": demo.get("n_episodes", 100), "difficulty": demo.get("difficulty", "medium"),
+                          "save_path": demo.get("save_path"),
                           "epochs": bc.get("epochs", 10), "batch_size": bc.get("batch_size", 256),
                           "learning_rate": bc.get("learning_rate", 1e-3)}
     return c

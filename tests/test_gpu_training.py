@@ -445,14 +445,14 @@ def test_train_with_imitation_cli(tmp_path, residual):
     assert np.isfinite(ev2["mean_reward"])
 
 
-def test_train_rate_accepts_the_overnight_schema(tmp_path):
+def test_train_rate_accepts_the_overnight_schema(tmp_path, capsys):
     """A train_overnight.py-style YAML (network / parallel / approach / demonstrations ...) through train_rate: imitation from
     the file's own settings, MLP policy, two curriculum phases."""
     import yaml
     from hcrl_amd import train_rate
     cfg = yaml.safe_load("""
 approach: {use_imitation: true, use_residual: false, use_curriculum: true}
-demonstrations: {n_episodes: 64, difficulty: easy, save_path: unused.pkl}
+demonstrations: {n_episodes: 64, difficulty: easy, save_path: DEMO_PATH}
 behavior_cloning: {epochs: 2, batch_size: 256, learning_rate: 0.001}
 curriculum:
   phases:
@@ -469,11 +469,29 @@ logging: {log_interval: 10, verbose: 1}
 seed: 7
 """)
     cfg["paths"] = {"model_dir": str(tmp_path / "m"), "tensorboard_log": str(tmp_path / "tb"), "best_model": str(tmp_path / "best")}
+    cfg["demonstrations"]["save_path"] = str(tmp_path / "demos" / "pid_demos.pkl")
     p = tmp_path / "overnight.yaml"
     p.write_text(yaml.safe_dump(cfg))
     train_rate.main(["--config", str(p)])
     ck = torch.load(tmp_path / "m" / "final_model.pt", weights_only=True)
     assert ck["num_timesteps"] == 2 * 8192 and not any(k.startswith("lstm_actor") for k in ck["policy"])
+    # train_overnight.py:116-183: the demonstrations are kept (data-only .npz) and the cloned policy is saved before PPO
+    demos = np.load(tmp_path / "demos" / "pid_demos.pkl.npz")
+    assert demos["observations"].shape[1] == 18 and demos["actions"].shape == (len(demos["observations"]), 4)
+    bc = torch.load(tmp_path / "m" / "bc_pretrained.pt", weights_only=True)
+    assert bc["num_timesteps"] == 0
+    # the reference's entry point: same flags, callbacks always on; --skip-demos reuses the file, --skip-bc skips cloning
+    from hcrl_amd import train_overnight
+    stamp = os.path.getmtime(tmp_path / "demos" / "pid_demos.pkl.npz")
+    os.remove(tmp_path / "m" / "bc_pretrained.pt")
+    train_overnight.main(["--config", str(p), "--skip-demos"])
+    assert os.path.getmtime(tmp_path / "demos" / "pid_demos.pkl.npz") == stamp and (tmp_path / "m" / "bc_pretrained.pt").exists()
+    out = capsys.readouterr().out
+    assert "OVERNIGHT TRAINING" in out and "Loading existing demos" in out and "TRAINING COMPLETE!" in out
+    assert (tmp_path / "tb" / "progress.jsonl").exists() and any(f.startswith("events.out.tfevents.") for f in os.listdir(tmp_path / "tb"))
+    os.remove(tmp_path / "m" / "bc_pretrained.pt")
+    train_overnight.main(["--config", str(p), "--skip-bc"])
+    assert not (tmp_path / "m" / "bc_pretrained.pt").exists() and "BC losses" not in capsys.readouterr().out
 
 
 def test_episode_statistics_of_training_rollouts():
