@@ -203,5 +203,6 @@ seed: 42
     assert b["lstm"]["enabled"] is False and b["mlp"]["net_arch"] == [256, 256, 128] and b["training"]["n_envs"] == 8
     assert b["training"]["total_timesteps"] == 11000000 and b["curriculum"]["enabled"] and b["environment"]["difficulty"] == "easy"
     assert b["training"]["save_freq"] == 500000 and b["training"]["eval_freq"] == 100000 and b["paths"]["model_save_dir"] == "md"
-    assert b["imitation"] == {"n_episodes": 500, "difficulty": "easy", "epochs": 20, "batch_size": 256, "learning_rate": 0.001}
+    assert b["imitation"] == {"n_episodes": 500, "difficulty": "easy", "save_path": "x.pkl", "epochs": 20, "batch_size": 256,
+                              "learning_rate": 0.001}
     assert PPOConfig.from_dict(b["ppo"]).n_steps == 2048
