@@ -208,3 +208,43 @@ def test_recover_training_picks_copies_and_verifies(tmp_path, capsys):
     (ck / "rate_controller_500_steps.pt").write_bytes(b"not a checkpoint")
     with pytest.raises(SystemExit):                                       # copy succeeds, verification fails
         recover_training.main(["--checkpoint-step", "500", "--output", str(out), "--checkpoint-dir", str(ck)])
+
+
+def test_aircraft_interface_contract():
+    """interfaces/aircraft.py:20-175 defaults, exercised the way the reference's tests/test_interfaces.py:163-272 does."""
+    from hcrl_amd.backend import AircraftInterface
+    from hcrl_amd.flight_types import ControlSurfaces
+
+    with pytest.raises(TypeError):
+        AircraftInterface()
+
+    class Craft(AircraftInterface):
+        def __init__(self, backend_type="simulation"):
+            self.backend_type, self.state, self.controls = backend_type, AircraftState(), ControlSurfaces()
+
+        def step(self, dt):
+            self.state.time += dt
+            self.state.altitude += dt * 10.0
+            return self.state
+
+        def set_controls(self, surfaces):
+            self.controls = surfaces
+
+        def reset(self, initial_state=None):
+            self.state = initial_state if initial_state is not None else AircraftState(altitude=100.0, airspeed=20.0)
+            return self.state
+
+        def get_state(self):
+            return self.state
+
+        def get_backend_type(self):
+            return self.backend_type
+
+    sim, hw, hil = Craft(), Craft("hardware"), Craft("hil")
+    assert sim.reset().altitude == 100.0
+    sim.set_controls(ControlSurfaces(elevator=0.1, throttle=0.7))
+    assert sim.controls.elevator == 0.1 and sim.step(dt=0.1).altitude == 101.0 and sim.get_state().time == 0.1
+    assert not sim.is_real_hardware() and hw.is_real_hardware() and hil.is_real_hardware()
+    assert sim.supports_reset() and not hw.supports_reset()
+    assert sim.get_dt_nominal() == 0.01 and sim.get_info() == {"backend_type": "simulation", "dt_nominal": 0.01}
+    assert sim.close() is None and repr(sim) == "Craft(type=simulation)"
