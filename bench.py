@@ -342,6 +342,11 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON: whatever libraries print there (gloo's "[Gloo] Rank ..." lines, RCCL
+    # warnings) is sent to stderr for the whole run, and the result is written to the saved descriptor at the end
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     world, rank, _ = setup_dist(args)
     wl = Workload(args, rank)
     wall, dev_ms, mode = timed_region(wl, args, world)
@@ -391,7 +396,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args)
         except Exception as ex:  # the oracle is optional test infrastructure; never fail the measurement over it
             out["cpu_baseline"] = {"value": None, "error": repr(ex)}
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.write(result_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":
