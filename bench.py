@@ -20,6 +20,7 @@ import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs between ranks on this driver stack
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -42,6 +42,7 @@ def main(argv=None):
     ap.add_argument("--device-index", type=int, default=-1, help="force every rank onto this GPU (one-GPU rehearsal of N > 1)")
     args = ap.parse_args(argv)
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs between ranks on this driver stack
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dev_index = args.device_index if args.device_index >= 0 else local
