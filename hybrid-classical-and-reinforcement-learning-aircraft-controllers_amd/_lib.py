@@ -47,6 +47,8 @@ SIGNATURES = {
     "fdyn_policy_heads": (_i, [_p, _p, _p, _p, _p, _p, _p, _u64, _p, _i, _p, _p, _p, _i64, _p]),
     "fdyn_gae": (_i, [_p, _p, _p, _p, _p, _f, _f, _i, _i64, _p, _p, _p]),
     "fdyn_rate_metrics_f64": (_i, [_p, _p, _p, _p, _p, _p, _d, _i, _i, _i64, _p, _p]),
+    "fdyn_rate_reward_seq_f64": (_i, [_p, _p, _p, _p, _p, _p, _p, _d, _i, _i64, _p, _p, _p, _p, _p]),
+    "fdyn_rate_reward_seq_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _i, _i64, _p, _p, _p, _p, _p]),
     "fdyn_sensor_update_f64": (_i, [_p, _p, _p, _p, _p, _u64, _p, _p, _i64, _p]),
     "fdyn_sensor_update_f32": (_i, [_p, _p, _p, _p, _p, _u64, _p, _p, _i64, _p]),
     "fdyn_sensor_observe": (_i, [_p, _p, _p, _p, _p, _u64, _p, _i64, _p]),

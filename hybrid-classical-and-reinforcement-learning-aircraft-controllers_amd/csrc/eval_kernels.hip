@@ -12,8 +12,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/fdyn.h"
+#include "fdyn_core.hpp"
 
 namespace {
+
+using namespace fdyn;
 
 template <typename S>
 __global__ void __launch_bounds__(256)
@@ -145,6 +148,102 @@ int launch_metrics(const double* times, const S* rates, const S* commands, const
     return int(hipGetLastError());
 }
 
+// RateTrackingReward.compute + SettlingTimeBonus.compute over recorded sequences (rewards.py:75-137,193-221): the operation
+// order of env_reward (fdyn_core.hpp), with the weights as parameters and the components written out.
+template <typename S>
+__global__ void __launch_bounds__(256)
+rate_reward_seq_kernel(const S* __restrict__ errs /*[T][3][n]*/, const S* __restrict__ actions /*[T][4][n]*/,
+                       const S* __restrict__ prev0 /*[4][n]*/, const S* __restrict__ flight /*[T][FD_NRF][n]*/,
+                       const S* __restrict__ cmd /*[3][n]*/, const double* __restrict__ params /*[FD_NRW]*/,
+                       S* __restrict__ rstate /*[FD_NRS][n]*/, S dt, int T, int64_t n, S* __restrict__ tracking,
+                       S* __restrict__ components, S* __restrict__ settle, uint8_t* __restrict__ settled)
+{
+#pragma clang fp contract(off)
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const S w_track = S(params[FD_RW_TRACKING]), w_smooth = S(params[FD_RW_SMOOTHNESS]), w_stab = S(params[FD_RW_STABILITY]);
+    const S w_osc = S(params[FD_RW_OSCILLATION]), w_surv = S(params[FD_RW_SURVIVAL]);
+    const S thr = S(params[FD_RW_SETTLE_THRESHOLD]), min_t = S(params[FD_RW_MIN_SETTLE_TIME]), mult = S(params[FD_RW_BONUS_MULTIPLIER]);
+    S perr[3], sc[3], c[3], prev[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        perr[k] = rstate[int64_t(FD_RS_PERR_P + k) * n + i];
+        sc[k] = rstate[int64_t(FD_RS_SIGN_P + k) * n + i];
+        c[k] = cmd[int64_t(k) * n + i];
+        prev[k] = prev0[int64_t(k) * n + i];
+    }
+    S timer = rstate[int64_t(FD_RS_SETTLE_TIMER) * n + i], is_settled = rstate[int64_t(FD_RS_IS_SETTLED) * n + i];
+    for (int t = 0; t < T; ++t) {
+        S err[3], a[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            err[k] = errs[(int64_t(t) * 3 + k) * n + i];
+            a[k] = actions[(int64_t(t) * 4 + k) * n + i];
+        }
+        const S airspeed = flight[(int64_t(t) * FD_NRF + FD_RF_AIRSPEED) * n + i];
+        const S altitude = flight[(int64_t(t) * FD_NRF + FD_RF_ALTITUDE) * n + i];
+        const S roll = flight[(int64_t(t) * FD_NRF + FD_RF_ROLL) * n + i], pitch = flight[(int64_t(t) * FD_NRF + FD_RF_PITCH) * n + i];
+        const S tracking_error = (err[0] * err[0] + err[1] * err[1] + err[2] * err[2]) / S(3);           // :76
+        const S r_tracking = -w_track * tracking_error;
+        const S d0 = a[0] - prev[0], d1 = a[1] - prev[1], d2 = a[2] - prev[2];
+        const S r_smooth = -w_smooth * (d0 * d0 + (d1 * d1 + d2 * d2));                                  // np.sum of 3: a0 + (a1 + a2)
+        const S roll_st = M<S>::exp(-M<S>::abs(roll) / deg2rad<S>(45.0));
+        const S pitch_st = M<S>::exp(-M<S>::abs(pitch) / deg2rad<S>(30.0));
+        const S as_st = clipv((airspeed - S(8)) / S(12), S(0), S(1));
+        const S alt_st = clipv((altitude - S(10)) / S(90), S(0), S(1));
+        const S r_stab = w_stab * ((roll_st + pitch_st + as_st + alt_st) / S(4));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const bool flip = (signv(err[k]) != signv(perr[k])) && (M<S>::abs(perr[k]) > S(0.01));
+            sc[k] = S(0.9) * sc[k] + (flip ? S(1) : S(0));
+            perr[k] = err[k];
+            prev[k] = a[k];
+        }
+        const S r_osc = -w_osc * (sc[0] + (sc[1] + sc[2]));
+        const S total = r_tracking + r_smooth + r_stab + r_osc + w_surv;
+        bool now = true;                                                                                  // :193-209
+#pragma unroll
+        for (int k = 0; k < 3; ++k) now = now && (M<S>::abs(err[k]) < pymax(M<S>::abs(c[k]) * thr, S(0.05)));
+        S bonus = S(0);
+        if (now) {
+            timer += dt;
+            if (timer >= min_t) { is_settled = S(1); bonus = mult * dt; }
+        } else {
+            timer = S(0);
+            is_settled = S(0);
+        }
+        if (tracking) tracking[int64_t(t) * n + i] = total;
+        if (components) {
+            components[(int64_t(t) * FD_NRC + FD_RC_TRACKING) * n + i] = r_tracking;
+            components[(int64_t(t) * FD_NRC + FD_RC_SMOOTHNESS) * n + i] = r_smooth;
+            components[(int64_t(t) * FD_NRC + FD_RC_STABILITY) * n + i] = r_stab;
+            components[(int64_t(t) * FD_NRC + FD_RC_OSCILLATION) * n + i] = r_osc;
+            components[(int64_t(t) * FD_NRC + FD_RC_SURVIVAL) * n + i] = w_surv;
+        }
+        if (settle) settle[int64_t(t) * n + i] = bonus;
+        if (settled) settled[int64_t(t) * n + i] = is_settled != S(0) ? 1 : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        rstate[int64_t(FD_RS_PERR_P + k) * n + i] = perr[k];
+        rstate[int64_t(FD_RS_SIGN_P + k) * n + i] = sc[k];
+    }
+    rstate[int64_t(FD_RS_SETTLE_TIMER) * n + i] = timer;
+    rstate[int64_t(FD_RS_IS_SETTLED) * n + i] = is_settled;
+}
+
+template <typename S>
+int launch_reward_seq(const S* errs, const S* actions, const S* prev0, const S* flight, const S* cmd, const double* params,
+                      S* rstate, S dt, int T, int64_t n, S* tracking, S* components, S* settle, uint8_t* settled, void* stream)
+{
+    if (n < 0 || T < 0) return FDYN_ERR_BAD_SIZE;
+    if (n == 0) return FDYN_OK;
+    if (!params || !rstate || !cmd || !prev0 || (T > 0 && (!errs || !actions || !flight))) return FDYN_ERR_NULL;
+    hipLaunchKernelGGL(rate_reward_seq_kernel<S>, dim3(unsigned((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, errs, actions,
+                       prev0, flight, cmd, params, rstate, dt, T, n, tracking, components, settle, settled);
+    return int(hipGetLastError());
+}
+
 }  // namespace
 
 extern "C" {
@@ -163,6 +262,20 @@ int fdyn_rate_metrics_f32(const double* times, const float* rates, const float* 
 {
     return launch_metrics<float>(times, rates, commands, actions, rewards, lengths, settling_threshold, settle_steps, T, n,
                                  out, stream);
+}
+
+int fdyn_rate_reward_seq_f64(const double* errs, const double* actions, const double* prev0, const double* flight,
+                             const double* cmd, const double* params, double* rstate, double dt, int T, int64_t n,
+                             double* tracking, double* components, double* settle, uint8_t* settled, void* stream)
+{
+    return launch_reward_seq<double>(errs, actions, prev0, flight, cmd, params, rstate, dt, T, n, tracking, components, settle, settled, stream);
+}
+
+int fdyn_rate_reward_seq_f32(const float* errs, const float* actions, const float* prev0, const float* flight,
+                             const float* cmd, const double* params, float* rstate, float dt, int T, int64_t n,
+                             float* tracking, float* components, float* settle, uint8_t* settled, void* stream)
+{
+    return launch_reward_seq<float>(errs, actions, prev0, flight, cmd, params, rstate, dt, T, n, tracking, components, settle, settled, stream);
 }
 
 }  // extern "C"

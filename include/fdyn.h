@@ -29,6 +29,8 @@
  *                                                            learned_controllers/envs/rate_env.py:212-300,342-460,
  *                                                            learned_controllers/envs/rewards.py:48-137,168-221
  *   fdyn_rate_metrics_*    MetricsCalculator.compute_metrics learned_controllers/eval/metrics.py:95-362 (fed by eval_rate.py:70-233)
+ *   fdyn_rate_reward_seq_* RateTrackingReward.compute / SettlingTimeBonus.compute on recorded sequences (weights as parameters,
+ *                          components out)                     learned_controllers/envs/rewards.py:48-137,168-221
  *   fdyn_sensor_update_*   NoisySensorInterface.update       interfaces/sensor.py:199-243
  *   fdyn_sensor_observe    the same noise model on RateControlEnv observations (rate_env.py:374-408 layout)
  * Policy side (the reference delegates these to torch.nn.LSTM / SB3's PPO, which are not in its tree):
@@ -230,6 +232,22 @@ int fdyn_rate_metrics_f64(const double* times, const double* rates, const double
 int fdyn_rate_metrics_f32(const double* times, const float* rates, const float* commands, const float* actions,
                           const float* rewards, const int32_t* lengths, double settling_threshold, int settle_steps,
                           int T, int64_t n, double* out, void* stream);
+
+
+/* ---- rewards on recorded data (csrc/eval_kernels.hip) -----------------------------------------------------------------
+ * RateTrackingReward.compute + SettlingTimeBonus.compute (learned_controllers/envs/rewards.py:48-137,168-221) over n
+ * independent sequences of T steps, one sequence per lane -- the same arithmetic the fused env step applies
+ * (rate_env.py:248-279), here with the reference's configurable weights and with the per-step components the env step
+ * does not materialise.  errs [T][3][n]; actions [T][4][n] ([aileron, elevator, rudder, throttle]); prev0 [4][n] = the
+ * action before step 0 (later steps use the previous row); flight [T][FD_NRF][n]; cmd [3][n]; params [FD_NRW] fp64;
+ * rstate [FD_NRS][n] in/out (zeros = reset()).  Outputs (any may be NULL): tracking [T][n] (the RateTrackingReward total),
+ * components [T][FD_NRC][n], settle [T][n] (the bonus of each step), settled [T][n] uint8 (is_settled after the step). */
+int fdyn_rate_reward_seq_f64(const double* errs, const double* actions, const double* prev0, const double* flight,
+                             const double* cmd, const double* params, double* rstate, double dt, int T, int64_t n,
+                             double* tracking, double* components, double* settle, uint8_t* settled, void* stream);
+int fdyn_rate_reward_seq_f32(const float* errs, const float* actions, const float* prev0, const float* flight,
+                             const float* cmd, const double* params, float* rstate, float dt, int T, int64_t n,
+                             float* tracking, float* components, float* settle, uint8_t* settled, void* stream);
 
 
 /* ---- sensor layer (csrc/sensor_kernels.hip) ---------------------------------------------------------------------------

@@ -131,6 +131,22 @@ enum {
     FD_NM = 17
 };
 
+/* ---- stand-alone reward evaluation (fdyn_rate_reward_seq_*), learned_controllers/envs/rewards.py ------------------- */
+/* parameters (fp64): RateTrackingReward weights :14-19, then SettlingTimeBonus :160-162                              */
+enum {
+    FD_RW_TRACKING = 0, FD_RW_SMOOTHNESS, FD_RW_STABILITY, FD_RW_OSCILLATION, FD_RW_SURVIVAL,
+    FD_RW_SETTLE_THRESHOLD, FD_RW_MIN_SETTLE_TIME, FD_RW_BONUS_MULTIPLIER,
+    FD_NRW = 8
+};
+/* carried state per sequence: RateTrackingReward.prev_errors / sign_changes (:37-38), SettlingTimeBonus timer / flag */
+enum {
+    FD_RS_PERR_P = 0, FD_RS_PERR_Q, FD_RS_PERR_R, FD_RS_SIGN_P, FD_RS_SIGN_Q, FD_RS_SIGN_R, FD_RS_SETTLE_TIMER, FD_RS_IS_SETTLED,
+    FD_NRS = 8
+};
+/* reward components in the order of the reference's dict (:125-131); flight rows of the input                        */
+enum { FD_RC_TRACKING = 0, FD_RC_SMOOTHNESS, FD_RC_STABILITY, FD_RC_OSCILLATION, FD_RC_SURVIVAL, FD_NRC = 5 };
+enum { FD_RF_AIRSPEED = 0, FD_RF_ALTITUDE, FD_RF_ROLL, FD_RF_PITCH, FD_NRF = 4 };
+
 /* ---- sensor layer, interfaces/sensor.py:137-243 (NoisySensorInterface) ------------------------------------------- */
 /* noise configuration (fp64): standard deviations in the order the reference draws (:208-235), then the two bias
  * random-walk steps it hard-codes (:233-234) and the enabled flag (:203-205)                                        */
