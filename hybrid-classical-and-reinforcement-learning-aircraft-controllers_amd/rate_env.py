@@ -106,6 +106,8 @@ class GpuRateVecEnv:
         if actions is not None:
             actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
             assert actions.shape == (self.n, L.FD_ACT_DIM)
+        if rw_delta is not None:                               # random-walk command increments [3][N] in the state dtype
+            assert rw_delta.shape == (3, self.n) and rw_delta.dtype == self.dtype and rw_delta.device == self.x.device
         cur, nxt = self._ev_counts[self._ev_slot:self._ev_slot + 1], self._ev_counts[1 - self._ev_slot:2 - self._ev_slot]
         self.ev_count, self._ev_slot = cur, 1 - self._ev_slot
         rc = self._step_fn(_lib.ptr(self.x), _lib.ptr(self.e), _lib.ptr(self.ei), _lib.ptr(self.type_index),
