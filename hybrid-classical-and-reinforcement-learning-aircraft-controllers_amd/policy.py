@@ -304,8 +304,8 @@ class RateLSTMPolicy(nn.Module):
                     pi_seq, vf_seq = h_seq[:, 0], h_seq[:, 1]
                 else:
                     # large slices fill the chip per cell; the batched GEMM is then slower than two plain ones (74 vs 68 ms)
-                    pi_seq = lstm_sequence(feats, cells[:1], pi_h.to(dt).unsqueeze(0), pi_c.unsqueeze(0), keep_all)[0][:, 0]
-                    vf_seq = lstm_sequence(feats, cells[1:], vf_h.to(dt).unsqueeze(0), vf_c.unsqueeze(0), keep_all)[0][:, 0]
+                    pi_seq = lstm_sequence(feats, cells[:1], pi_h.to(dt).unsqueeze(0), pi_c.unsqueeze(0), keep_all)[0].squeeze(1)
+                    vf_seq = lstm_sequence(feats, cells[1:], vf_h.to(dt).unsqueeze(0), vf_c.unsqueeze(0), keep_all)[0].squeeze(1)
                 mean = linear(_run_seq(self.pi_net, pi_seq), self.action_net.weight, self.action_net.bias).float()
                 values = linear(_run_seq(self.vf_net, vf_seq), self.value_net.weight, self.value_net.bias).float().squeeze(-1)
                 return values, mean
