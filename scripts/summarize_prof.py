@@ -22,7 +22,17 @@ def short(name):
 
 
 # ---- kernel-trace --stats ---------------------------------------------------------------------------------
-stats = glob.glob(os.path.join(prof, "trace", "**", "*_kernel_stats.csv"), recursive=True)
+def newest_per_dir(paths):
+    """gpurun merges every call's files into the same local directories: keep the most recent file of each directory."""
+    best = {}
+    for q in paths:
+        d = os.path.dirname(q)
+        if d not in best or os.path.getmtime(q) > os.path.getmtime(best[d]):
+            best[d] = q
+    return sorted(best.values())
+
+
+stats = newest_per_dir(glob.glob(os.path.join(prof, "trace", "**", "*_kernel_stats.csv"), recursive=True))
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
     with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w") as f:
@@ -36,7 +46,7 @@ if stats:
 # ---- PMC passes: average per dispatch of the hot kernels ------------------------------------------------------
 pmc = defaultdict(lambda: defaultdict(list))
 meta = {}
-for path in glob.glob(os.path.join(prof, "p*", "**", "*_counter_collection.csv"), recursive=True):
+for path in newest_per_dir(glob.glob(os.path.join(prof, "p*", "**", "*_counter_collection.csv"), recursive=True)):
     for r in csv.DictReader(open(path)):
         k = short(r["Kernel_Name"])
         if not any(s in k for s in ("rate_env", "sixdof", "cascade", "lstm", "gate")):
