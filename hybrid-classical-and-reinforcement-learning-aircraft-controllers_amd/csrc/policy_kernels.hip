@@ -152,7 +152,12 @@ lstm_cell_bwd_kernel(const GT* act /*may alias dgates: every lane reads its 4 x 
     float ai[VEC], af[VEC], ag[VEC], ao[VEC], cp[VEC], cn[VEC], dhv[VEC], dcn[VEC];
     float di[VEC], df[VEC], dg[VEC], dov[VEC], dcp[VEC];
     Vec8<GT>::load(a0, ai); Vec8<GT>::load(a0 + H, af); Vec8<GT>::load(a0 + 2 * H, ag); Vec8<GT>::load(a0 + 3 * H, ao);
-    Vec8<float>::load(c_new + row * H + j, cn);
+    if (c_new) {
+        Vec8<float>::load(c_new + row * H + j, cn);
+    } else {                                              // zero-state cell whose c was not kept: c = i * g from the saved gates
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) cn[k] = ai[k] * ag[k];
+    }
     Vec8<GT>::load(dh + row * H + j, dhv);
     if (c_prev) Vec8<float>::load(c_prev + row * H + j, cp);
     if (dc_next) Vec8<float>::load(dc_next + row * H + j, dcn);
@@ -603,7 +608,7 @@ int fdyn_lstm_cell_bwd(const void* act, int bf16, const float* c_prev, const flo
                        const float* dc_next, void* dgates, float* dc_prev, int64_t B, int H, void* stream)
 {
     if (B < 0 || H <= 0 || H % VEC) return FDYN_ERR_BAD_SIZE;
-    if (!act || !c_new || !dh || !dgates) return FDYN_ERR_NULL;
+    if (!act || !dh || !dgates || (!c_new && c_prev)) return FDYN_ERR_NULL;     // c_new may be NULL only for a zero-state cell
     if (B == 0) return FDYN_OK;
     const int64_t tv = B * (H / VEC);
     if (bf16)

@@ -20,7 +20,7 @@ def _lstm_cell_torch(gates, c_prev):
 
 class _LSTMCellFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, gates, c_prev):
+    def forward(ctx, gates, c_prev, need_c=True):
         lib = _lib.load()
         gates = gates.contiguous()
         B, H4 = gates.shape
@@ -34,21 +34,27 @@ class _LSTMCellFn(torch.autograd.Function):
         # [B, H] fp32 zero tensor: that fill + the kernel reading it back cost ~150 us per layer per slice at 524 288 rows
         ctx.set_materialize_grads(False)
         h = torch.empty((B, H), dtype=gates.dtype, device=gates.device)
-        c = torch.empty((B, H), dtype=torch.float32, device=gates.device)
+        # need_c=False (zero-state cells whose caller only wants h -- the feature extractor's layers): c is neither written
+        # nor kept, the backward rebuilds c = i * g from the saved gates; 18 % of each kernel's traffic at 524 288 rows
+        assert need_c or c_prev is None, "only a zero-state cell can drop its cell state"
+        c = torch.empty((B, H), dtype=torch.float32, device=gates.device) if need_c else None
         act = torch.empty_like(gates) if need_grad else None
-        _lib.check(lib.fdyn_lstm_cell_fwd(gates.data_ptr(), int(bf16), _lib.ptr(c_prev), None, h.data_ptr(), c.data_ptr(),
+        _lib.check(lib.fdyn_lstm_cell_fwd(gates.data_ptr(), int(bf16), _lib.ptr(c_prev), None, h.data_ptr(), _lib.ptr(c),
                                           _lib.ptr(act), B, H, _lib.current_stream()), "lstm_cell_fwd")
         if need_grad:
-            ctx.save_for_backward(act, c_prev, c)
-            ctx.has_prev = c_prev is not None
+            ctx.has_prev, ctx.has_c = c_prev is not None, need_c
+            ctx.save_for_backward(*([act] + ([c_prev] if ctx.has_prev else []) + ([c] if need_c else [])))
         return h, c
 
     @staticmethod
     def backward(ctx, dh, dc):
         if dh is None and dc is None:
-            return None, None
+            return None, None, None
         lib = _lib.load()
-        act, c_prev, c = ctx.saved_tensors if ctx.has_prev else (ctx.saved_tensors[0], None, ctx.saved_tensors[-1])
+        saved = list(ctx.saved_tensors)
+        act = saved.pop(0)
+        c_prev = saved.pop(0) if ctx.has_prev else None
+        c = saved.pop(0) if ctx.has_c else None
         B, H4 = act.shape
         H = H4 // 4
         bf16 = act.dtype == torch.bfloat16
@@ -56,17 +62,19 @@ class _LSTMCellFn(torch.autograd.Function):
         dc = None if dc is None else dc.float().contiguous()
         dgates = torch.empty_like(act)
         dc_prev = torch.empty((B, H), dtype=torch.float32, device=act.device) if ctx.has_prev else None
-        _lib.check(lib.fdyn_lstm_cell_bwd(act.data_ptr(), int(bf16), _lib.ptr(c_prev), c.data_ptr(), dh.data_ptr(),
+        _lib.check(lib.fdyn_lstm_cell_bwd(act.data_ptr(), int(bf16), _lib.ptr(c_prev), _lib.ptr(c), dh.data_ptr(),
                                           _lib.ptr(dc), dgates.data_ptr(), _lib.ptr(dc_prev), B, H, _lib.current_stream()),
                    "lstm_cell_bwd")
-        return dgates, dc_prev
+        return dgates, dc_prev, None
 
 
-def lstm_cell(gates: torch.Tensor, c_prev: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
-    """gates [B, 4H] pre-activation (i, f, g, o), c_prev [B, H] fp32 or None (zero state) -> h [B, H] (gates dtype), c fp32."""
+def lstm_cell(gates: torch.Tensor, c_prev: Optional[torch.Tensor], need_c: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """gates [B, 4H] pre-activation (i, f, g, o), c_prev [B, H] fp32 or None (zero state) -> h [B, H] (gates dtype), c fp32.
+    need_c=False (zero state only): the caller wants h alone -- c comes back as None and is never stored."""
     if gates.is_cuda:
-        return _LSTMCellFn.apply(gates, c_prev)
-    return _lstm_cell_torch(gates, c_prev)
+        return _LSTMCellFn.apply(gates, c_prev, need_c)
+    h, c = _lstm_cell_torch(gates, c_prev)
+    return h, (c if need_c else None)
 
 
 # ---- weight gradients of tall-skinny linears ---------------------------------------------------------------------------

@@ -56,7 +56,7 @@ def _lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh):
 
 
 def _lstm_zero_state_layer(x, w_ih, b_ih, b_hh):
-    return lstm_cell(linear(x, w_ih, b_ih + b_hh), None)[0]
+    return lstm_cell(linear(x, w_ih, b_ih + b_hh), None, need_c=False)[0]
 
 
 def _run_seq(seq, x):

@@ -159,7 +159,8 @@ FDYN_DECLARE_ENV(f32, float)
  * learned_controllers/networks/lstm_policy.py:49-61 and sb3_contrib's actor/critic LSTMs).
  * gates_bf16: 1 = bf16 storage for gates/h_lp/act/dh/dgates, 0 = fp32.  c_prev NULL = zero state.  H % 8 == 0.
  * fwd: h_f32 [B][H] and/or h_lp [B][H] (either may be NULL), c_out [B][H] fp32, act_out [B][4H] activated gates or NULL.
- * bwd: from act, c_prev, c_new, dh (+ dc_next or NULL) -> dgates [B][4H], dc_prev [B][H] (or NULL).                   */
+ * bwd: from act, c_prev, c_new, dh (+ dc_next or NULL) -> dgates [B][4H], dc_prev [B][H] (or NULL).  A zero-state cell
+ *      (c_prev NULL) may pass c_new NULL: c = i * g is then rebuilt from the saved gates (its forward need not keep c). */
 int fdyn_lstm_cell_fwd(const void* gates, int gates_bf16, const float* c_prev, float* h_f32, void* h_lp, float* c_out,
                        void* act_out, int64_t B, int H, void* stream);
 int fdyn_lstm_cell_bwd(const void* act, int bf16, const float* c_prev, const float* c_new, const void* dh,

@@ -88,6 +88,16 @@ def test_fused_lstm_cell_matches_plain_torch_fp32(dtype, tol, zero_state):
     assert (g.grad.float() - g32.grad).abs().max() < tol * 4
     if not zero_state:
         assert (c.grad - c32.grad).abs().max() < tol * 4
+    else:
+        # the h-only form of a zero-state cell (what the feature extractor's layers use): c is never stored, the backward
+        # rebuilds it from the saved gates -- same h, same gate gradient as the plain reference differentiated through h alone
+        g2 = g.detach().clone().requires_grad_()
+        h2, none_c = lstm_cell(g2, None, need_c=False)
+        assert none_c is None and torch.equal(h2, h)
+        (h2.float() * w_h).sum().backward()
+        gr = g32.detach().clone().requires_grad_()
+        (_lstm_cell_torch(gr, None)[0] * w_h).sum().backward()
+        assert (g2.grad.float() - gr.grad).abs().max() < tol * 4
 
 
 def test_fused_gae_matches_torch_loop():
