@@ -248,3 +248,24 @@ def test_aircraft_interface_contract():
     assert sim.supports_reset() and not hw.supports_reset()
     assert sim.get_dt_nominal() == 0.01 and sim.get_info() == {"backend_type": "simulation", "dt_nominal": 0.01}
     assert sim.close() is None and repr(sim) == "Craft(type=simulation)"
+
+
+def test_bench_usable_cores_respects_affinity_and_quota(monkeypatch, tmp_path):
+    """bench.py's CPU-baseline thread count: OpenMP's maximum capped by the affinity mask and the cgroup CPU quota."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n_aff = len(os.sched_getaffinity(0))
+    assert 1 <= bench.usable_cores(10 ** 6) <= n_aff and bench.usable_cores(1) == 1
+    real_open = open
+
+    def fake_open(path, *a, **k):
+        if path == "/sys/fs/cgroup/cpu.max":
+            import io
+            return io.StringIO("200000 100000\n")                    # a quota of two cores
+        return real_open(path, *a, **k)
+    monkeypatch.setattr("builtins.open", fake_open)
+    assert bench.usable_cores(10 ** 6) == min(2, n_aff)
+    assert isinstance(bench.cpu_model(), str)
