@@ -186,7 +186,9 @@ def timed_region(wl, args, world):
         stream.wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread-local capture mode: with N > 1 the process group's watchdog thread may touch the HIP runtime while this
+        # thread captures; only calls made by the capturing thread should be able to invalidate the capture
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             for k in range(gsteps):
                 wl.step(k)
 

@@ -237,7 +237,7 @@ class RecurrentPPO:
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
                 self._graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._graph):
+                with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
                     self._rollout_body()
                 self._graph_env = self.env
             self._graph.replay()                          # the whole T-step rollout is ONE graph launch
@@ -280,7 +280,7 @@ class RecurrentPPO:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             g["stats"] = body()
         g["graph"], g["mb"] = graph, mb
         return g
