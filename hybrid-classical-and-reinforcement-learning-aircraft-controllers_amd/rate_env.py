@@ -129,16 +129,65 @@ class GpuRateVecEnv:
 
     def step(self, actions, auto_reset: bool = True):
         if isinstance(actions, np.ndarray):
-            actions = torch.as_tensor(actions, dtype=torch.float32, device=self.device)
+            if self.numpy_io and actions.shape == (self.n, L.FD_ACT_DIM):        # pinned staging: one async H2D, no pageable copy
+                io = self._host_io()
+                np.copyto(io["act_np"], actions, casting="same_kind")
+                io["act_dev"].copy_(io["act"], non_blocking=True)
+                actions = io["act_dev"]
+            else:
+                actions = torch.as_tensor(actions, dtype=torch.float32, device=self.device)
         rw = None
         if self._streams is not None:                                # parity-mode random-walk deltas for THIS step
             d = np.stack([s.random_walk_delta(self.dt) for s in self._streams], axis=1)
             rw = torch.as_tensor(np.ascontiguousarray(d), device=self.device).to(self.dtype)
         obs, rew, term, trunc = self.step_device(actions, auto_reset, rw)
-        dones = (term | trunc).bool()
         if self.numpy_io:
-            return obs.cpu().numpy(), rew.cpu().numpy(), dones.cpu().numpy(), self.episode_infos()
-        return obs, rew, dones, None
+            # everything the host needs leaves in ONE stream-ordered batch of async copies into pinned buffers, one sync
+            io = self._host_io()
+            torch.bitwise_or(term, trunc, out=io["done_dev"])
+            io["obs"].copy_(obs, non_blocking=True); io["rew"].copy_(rew, non_blocking=True)
+            io["done"].copy_(io["done_dev"], non_blocking=True); io["count"].copy_(self.ev_count, non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()
+            k = min(int(io["count"][0]), self.ev_cap)
+            if k > 0:                                                # the records of the few episodes that just ended
+                io["ev_int"][:k].copy_(self.ev_int[:k], non_blocking=True)
+                io["ev_flt"][:k].copy_(self.ev_flt[:k], non_blocking=True)
+                torch.cuda.current_stream(self.device).synchronize()
+            infos = self._infos_from(io["ev_int"][:k].numpy(), io["ev_flt"][:k].numpy())
+            return io["obs"].numpy().copy(), io["rew"].numpy().copy(), io["done"].numpy().astype(bool), infos
+        return obs, rew, (term | trunc).bool(), None
+
+    def _host_io(self):
+        """Pinned host staging buffers of the NumPy surface (allocated on first use)."""
+        if getattr(self, "_io", None) is None:
+            pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)                       # noqa: E731
+            act = pin((self.n, L.FD_ACT_DIM), torch.float32)
+            self._io = {"act": act, "act_np": act.numpy(), "act_dev": torch.empty((self.n, L.FD_ACT_DIM), dtype=torch.float32, device=self.device),
+                        "obs": pin(tuple(self.obs.shape), self.obs.dtype), "rew": pin(tuple(self.rewards.shape), self.rewards.dtype),
+                        "done": pin((self.n,), torch.uint8), "done_dev": torch.empty(self.n, dtype=torch.uint8, device=self.device),
+                        "count": pin((1,), self.ev_count.dtype), "ev_int": pin(tuple(self.ev_int.shape), self.ev_int.dtype),
+                        "ev_flt": pin(tuple(self.ev_flt.shape), self.ev_flt.dtype)}
+            self._info_list, self._info_dirty = [{} for _ in range(self.n)], []
+        return self._io
+
+    def _infos_from(self, ints, flts):
+        """The vec-env info list without building N dicts per step: entries of envs that finished get a fresh dict, the ones
+        written last step are reset, everything else stays the (empty) dict it was."""
+        lst = self._info_list
+        for i in self._info_dirty:
+            lst[i] = {}
+        dirty = []
+        for (env, length, term), f in zip(ints, flts):
+            lst[env] = {"episode": {"r": float(f[0]), "l": int(length)}, "terminal_observation": f[1:].copy(),
+                        "TimeLimit.truncated": not bool(term)}
+            dirty.append(int(env))
+        self._info_dirty = dirty
+        return list(lst)
+
+    def episode_events_host(self):
+        """(ints, floats) NumPy records of the episodes that ended in the last step."""
+        ints, flts = self.episode_events()
+        return ints.cpu().numpy(), flts.cpu().numpy()
 
     def step_async(self, actions):
         self._pending = actions
