@@ -214,3 +214,36 @@ def test_residual_rate_control_env_dropin_vs_reference_fixture():
     env.close()
     with pytest.raises(ValueError):
         ResidualRateControlEnv(residual_scale=0.0)
+
+
+def test_numpy_vec_env_surface_matches_device_surface():
+    """`numpy_io=True` (host arrays + per-env info dicts, the reference vec-env's convention via pinned staging) against the
+    device surface of an identically seeded env; info bookkeeping across steps."""
+    from hcrl_amd.rate_env import GpuRateVecEnv
+    n = 1000
+    host = GpuRateVecEnv(n, "hard", 1.0, 0.02, "step", seed=11, precision="f64", sampling="device", numpy_io=True)   # 50-step episodes
+    dev = GpuRateVecEnv(n, "hard", 1.0, 0.02, "step", seed=11, precision="f64", sampling="device")
+    o_h, o_d = host.reset(), dev.reset()
+    assert isinstance(o_h, np.ndarray) and np.array_equal(o_h, o_d.cpu().numpy())
+    rs = np.random.RandomState(0)
+    finished_last = set()
+    total_eps = 0
+    for k in range(120):
+        a = np.concatenate([rs.uniform(-1, 1, (n, 3)), rs.uniform(0, 1, (n, 1))], 1).astype(np.float32)
+        oh, rh, dh, infos = host.step(a)
+        od, rd, dd, none = dev.step(torch.as_tensor(a, device="cuda"))
+        assert none is None and oh.dtype == np.float32 and dh.dtype == np.bool_ and len(infos) == n
+        assert np.array_equal(oh, od.cpu().numpy()) and np.array_equal(rh, rd.cpu().numpy()) and np.array_equal(dh, dd.cpu().numpy())
+        ints, flts = dev.episode_events_host()
+        done_now = set(int(e) for e in ints[:, 0])
+        assert done_now == set(np.nonzero(dh)[0].tolist())
+        for (env, length, term), f in zip(ints, flts):
+            info = infos[env]
+            assert info["episode"] == {"r": float(f[0]), "l": int(length)} and info["TimeLimit.truncated"] == (not bool(term))
+            assert np.array_equal(info["terminal_observation"], f[1:]) and 1 <= length <= 50
+        for env in finished_last - done_now:                       # last step's records do not linger
+            assert infos[env] == {}
+        assert all(infos[i] == {} for i in range(n) if i not in done_now)
+        finished_last, total_eps = done_now, total_eps + len(done_now)
+        oh[:] = 0                                                   # returned arrays are the caller's: scribbling is harmless
+    assert total_eps >= 2 * n                                       # every env finished at least twice (truncation at 50 steps)
