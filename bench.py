@@ -2,7 +2,10 @@
 """bench.py -- env-steps/sec of the fused rate-control hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU; env batches shard with no data-path collective)
+    N > 1: one rank per GPU.  Started by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the
+    ranks read RANK / LOCAL_RANK / WORLD_SIZE; started plainly (`python bench.py --gpus N`, WORLD_SIZE unset) the parent
+    makes NO GPU call: it starts that launcher as a child process and relays rank 0's JSON line.  Env batches shard with
+    no data-path collective; the N > 1 line adds a short `train` leg whose flat-gradient all-reduce runs on RCCL.
 
 One "step" = one pass of the hot path over one batch: ONE fused launch of `rate_env_step` over 65 536 envs per GPU
 (action clip -> 20 RK4 sub-steps of the 6-DOF model -> command update -> reward -> termination -> observation ->
@@ -21,6 +24,44 @@ import time
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs between ranks on this driver stack
+
+
+
+def _self_launch_if_needed():
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start N ranks as a CHILD
+    `torch.distributed.run` and relay rank 0's line.  Runs before torch is imported, so this process never touches the GPU
+    (a process that has initialised the GPU must not exec or re-exec; children are fresh processes)."""
+    if "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    n = 1
+    argv = sys.argv[1:]
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE)          # stderr passes through; stdout carries rank 0's JSON line
+    line = None
+    for ln in proc.stdout.decode(errors="replace").splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if line is not None:
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+    sys.exit(proc.returncode if proc.returncode or line is not None else 1)
+
+
+if __name__ == "__main__":
+    _self_launch_if_needed()
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -60,6 +101,11 @@ def setup_dist(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        # a scaling point must be what it says it is: never print "n_gpus": 1 for a `--gpus 8` request or vice versa
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher environment says WORLD_SIZE={world}; start it as "
+                         f"`python bench.py --gpus {args.gpus}` (self-launching) or `python -m torch.distributed.run "
+                         f"--nproc-per-node {args.gpus} bench.py --gpus {args.gpus}`")
     dev = args.device_index if args.device_index >= 0 else local
     torch.cuda.set_device(dev)
     if world > 1:
@@ -171,84 +217,211 @@ class Workload:
             self.fleet.run(0.01, self.inner)
 
 
-def timed_region(wl, args, world):
-    """W warm-up steps, then EXACTLY K timed steps bracketed by barrier + synchronize; HIP events on the launch stream."""
+class StepLoop:
+    """Runs `n` steps of a workload: whole hipGraph replays of `gsteps` steps first, then eager leftovers.
+
+    The env's event counters (`GpuRateVecEnv._ev_slot`) and the policy's recurrent-state buffers (`RecurrentPPO._cur`)
+    ping-pong once per step on the HOST, and a captured graph bakes in the buffer pointers of the parity it was captured
+    at.  gsteps is even, so a replay preserves parity, but an odd eager tail flips it: one graph is therefore captured
+    per parity (before any timing) and the loop replays the one that matches the number of steps executed so far."""
+
+    def __init__(self, wl, args):
+        self.wl, self.count, self.graphs, self.gsteps = wl, 0, {}, 0
+        K = args.steps
+        if args.graph and K >= 2 and args.workload in ("env", "env_pid", "physics", "cascade", "rollout"):
+            self.gsteps = max(2, min(args.graph_steps, K) // 2 * 2)
+            stream = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(stream)
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    self._eager()                                  # warm the allocator / lazy init before capture
+            stream.wait_stream(side)
+            torch.cuda.synchronize()
+            for _ in range(2):
+                g = torch.cuda.CUDAGraph()
+                # thread-local capture mode: with N > 1 the process group's watchdog thread may touch the HIP runtime while
+                # this thread captures; only calls made by the capturing thread should be able to invalidate the capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    for _ in range(self.gsteps):
+                        self._eager()
+                self.count -= self.gsteps                          # captured, not executed
+                self.graphs[self.count % 2] = g
+                self._eager()                                      # one real step: the other parity
+            torch.cuda.synchronize()
+
+    def _eager(self):
+        self.wl.step(self.count)
+        self.count += 1
+
+    def run(self, nsteps):
+        done = 0
+        if self.graphs:
+            g = self.graphs[self.count % 2]
+            while nsteps - done >= self.gsteps:
+                g.replay()
+                done += self.gsteps
+                self.count += self.gsteps
+        for _ in range(nsteps - done):
+            self._eager()
+
+    @property
+    def mode(self):
+        return ("hipGraph x%d" % self.gsteps) if self.graphs else "eager"
+
+
+def timed_region(wl, args, world, min_region_s=0.05, max_repeats=31):
+    """W warm-up steps, then EXACTLY K timed steps bracketed by barrier + synchronize; HIP events on the launch stream.
+    When the K-step region is shorter than `min_region_s` (K = 20 launches of 68 us is 1.4 ms: two timer reads and a
+    launch-queue hiccup are a tenth of it) the same K-step region is timed R times and the MEDIAN is reported
+    (`repeats` in the output); K itself never changes."""
     K, W = args.steps, args.warmup
     stream = torch.cuda.current_stream()
-    graph, gsteps = None, 0
-    if args.graph and K >= 2 and args.workload in ("env", "env_pid", "physics", "cascade", "rollout"):
-        gsteps = max(2, min(args.graph_steps, K) // 2 * 2)          # even: the event counters ping-pong
-        side = torch.cuda.Stream()
-        side.wait_stream(stream)
-        with torch.cuda.stream(side):
-            for k in range(4):
-                wl.step(k)                                         # warm the allocator / lazy init before capture
-        stream.wait_stream(side)
+    loop = StepLoop(wl, args)
+    loop.run(W)
+
+    def once():
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if world > 1:
+            torch.distributed.barrier()
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        # thread-local capture mode: with N > 1 the process group's watchdog thread may touch the HIP runtime while this
-        # thread captures; only calls made by the capturing thread should be able to invalidate the capture
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            for k in range(gsteps):
-                wl.step(k)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        loop.run(K)
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        wall = time.perf_counter() - t0
+        dev_ms = ev0.elapsed_time(ev1)
+        if world > 1:
+            t = torch.tensor([wall], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            wall = float(t.item())
+        return wall, dev_ms
 
-    def run(nsteps):
-        done = 0
-        if graph is not None:
-            while nsteps - done >= gsteps:
-                graph.replay()
-                done += gsteps
-        for k in range(nsteps - done):
-            wl.step(k)
+    samples = [once()]
+    repeats = 1
+    if samples[0][0] < min_region_s:
+        repeats = int(min(max_repeats, max(3, (0.25 / max(samples[0][0], 1e-6)))) // 2 * 2 + 1)      # odd
+        if world > 1:                                              # every rank must take the same number of barriers
+            t = torch.tensor([repeats], dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
+            torch.distributed.broadcast(t, 0)
+            repeats = int(t.item())
+        samples += [once() for _ in range(repeats - 1)]
+    walls = sorted(s[0] for s in samples)
+    devs = sorted(s[1] for s in samples)
+    return walls[len(walls) // 2], devs[len(devs) // 2], loop.mode, {"repeats": repeats, "wall_min_s": walls[0], "wall_max_s": walls[-1]}
 
-    run(W)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+def train_leg(args, rank, world):
+    """The RCCL-exercising leg of the N > 1 line (and the `train` extra at N = 1): a few full PPO iterations -- rollout
+    graph, GAE, epochs x env-slices of BPTT, ONE flat all-reduce of the 7.3 MB gradient buffer per optimizer step -- with
+    the collective timed by HIP events on the stream that waits for it."""
+    import copy
+    a = copy.copy(args)
+    a.workload = "train"
+    wl = Workload(a, rank)
+    flat = wl.ppo.flat
+    iters, warm = 3, 1
+    for k in range(warm):
+        wl.step(k)
+    torch.cuda.synchronize()
+    flat.events = []
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ev0.record(stream)
-    run(K)
-    ev1.record(stream)
+    for k in range(iters):
+        wl.step(k)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
+    ar_ms = [e0.elapsed_time(e1) for e0, e1 in flat.events]
+    flat.events = None
     if world > 1:
         t = torch.tensor([wall], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         wall = float(t.item())
-    return wall, dev_ms, ("hipGraph x%d" % gsteps) if graph is not None else "eager"
+    opt_steps = a.ppo_epochs * a.ppo_minibatches
+    res = {"value": wl.units_per_step * iters * world / wall, "unit": "env-steps/s", "ms_per_iteration": wall * 1e3 / iters,
+           "iterations": iters, "workload": wl.desc, "optimizer_steps_per_iteration": opt_steps,
+           "policy": policy_block(wl, a, wall / iters, "train")}
+    if world > 1:
+        res["collective"] = {"op": "all_reduce(sum) of the flat fp32 gradient buffer", "backend": args.backend,
+                             "library": "RCCL over xGMI" if args.backend == "nccl" else "gloo (CPU rehearsal)",
+                             "n_ranks_in_group": torch.distributed.get_world_size(), "bytes": int(flat.buf.numel() * 4),
+                             "calls_timed": len(ar_ms), "allreduce_us_per_optimizer_step": 1e3 * sum(ar_ms) / max(len(ar_ms), 1),
+                             "allreduce_us_min": 1e3 * min(ar_ms) if ar_ms else None,
+                             "allreduce_us_max": 1e3 * max(ar_ms) if ar_ms else None,
+                             "note": "HIP events on the compute stream around the call: includes waiting for the slowest rank"}
+    del wl
+    torch.cuda.empty_cache()
+    return res
+
+
+def policy_block(wl, args, s_per_step, kind):
+    """MFMA side of a rollout / train workload: achieved policy TFLOP/s against the dense bf16 MFMA peak, plus the
+    MFMA-pipe occupancy of the recurrent cell from the committed PMC run (profiles/traffic.json)."""
+    mult = 1.0 if kind == "rollout" else (1.0 + 3.0 * args.ppo_epochs)      # fwd, or fwd + epochs x (fwd + bwd)
+    pf = wl.policy_flops * mult * wl.units_per_step / s_per_step / 1e12
+    peak = 2500.0 if args.policy_dtype == "bf16" else 157.3
+    blk = {"flops_per_env_step_fwd": wl.policy_flops, "achieved_tflops": pf, "dtype": args.policy_dtype,
+           "peak_tflops_dense": peak, "frac": pf / peak}
+    tpath = os.path.join(REPO, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        blk["lstm_cell_pmc"] = json.load(open(tpath)).get("lstm_mfma_65536")
+    return blk
 
 
 def extras(args):
     """Short secondary measurements (same GPU, same batch) reported beside the headline; each ~1-3 s."""
     import copy
     res = {}
+    drift = {}
+    dpath = os.path.join(REPO, "profiles", "drift.json")         # written by tests/test_gpu_parity_scale.py on the GPU box
+    if os.path.exists(dpath):
+        drift = json.load(open(dpath))
     # "*_saturation": the same kernels at a batch that fills the chip many times over (SURVEY 8d: "report physics-only
     # saturation throughput"): 4 Mi aircraft / 1 Mi envs per GPU -- what the hardware sustains once launch cost is amortised
-    for key, wl_name, steps, warm, batch in (("physics", "physics", 400, 40, None), ("cascade", "cascade", 100, 10, None),
-                                             ("rollout", "rollout", 60, 6, None), ("train", "train", 2, 1, None),
-                                             ("physics_20_substeps", "physics", 200, 20, None),
-                                             ("physics_saturation", "physics", 100, 10, 1 << 22),
-                                             ("env_saturation", "env", 60, 6, 1 << 20)):
+    for key, wl_name, steps, warm, batch, prec in (
+            ("env_f64", "env", 100, 10, None, "f64"), ("env_f32", "env", 200, 20, None, "f32"),
+            ("physics", "physics", 400, 40, None, None), ("cascade", "cascade", 100, 10, None, None),
+            ("rollout", "rollout", 60, 6, None, None),
+            ("physics_20_substeps", "physics", 200, 20, None, None),
+            ("physics_saturation", "physics", 100, 10, 1 << 22, None),
+            ("env_saturation", "env", 60, 6, 1 << 20, None)):
         try:
             a = copy.copy(args)
             a.workload, a.steps, a.warmup = wl_name, steps, warm
             if batch is not None:
                 a.batch = batch
+            if prec is not None:
+                a.precision = prec
             a.physics_substeps = 20 if key == "physics_20_substeps" else 1
             wl = Workload(a, 0)
-            wall, dev_ms, mode = timed_region(wl, a, 1)
-            wl_name = key
-            res[wl_name] = {"value": wl.units_per_step * steps / wall, "ms_per_step": wall * 1e3 / steps,
-                            "unit": "env-steps/s" if wl_name in ("rollout", "train", "env_saturation") else "aircraft-steps/s",
-                            "workload": wl.desc}
+            wall, dev_ms, mode, _rep = timed_region(wl, a, 1, min_region_s=0.0)
+            res[key] = {"value": wl.units_per_step * steps / wall, "ms_per_step": wall * 1e3 / steps,
+                        "unit": "env-steps/s" if wl_name in ("rollout", "env") else "aircraft-steps/s",
+                        "workload": wl.desc}
+            if key in ("env_f64", "env_f32"):
+                res[key]["precision"] = prec
+                res[key]["drift_vs_oracle"] = drift.get(prec)
+            if key == "rollout":
+                res[key]["policy"] = policy_block(wl, a, wall / steps, "rollout")
             del wl
             torch.cuda.empty_cache()
         except Exception as ex:
-            res[wl_name] = {"error": repr(ex)}
+            res[key] = {"error": repr(ex)}
+    for key, epochs in (("train", args.ppo_epochs), ("train_10_epochs", 10)):
+        # the second one is the reference's epoch count (learned_controllers/config/ppo_lstm.yaml:38-58: n_epochs 10)
+        try:
+            a = copy.copy(args)
+            a.ppo_epochs = epochs
+            res[key] = train_leg(a, 0, 1)
+        except Exception as ex:
+            res[key] = {"error": repr(ex)}
     return res
 
 
@@ -352,14 +525,21 @@ def main():
     os.dup2(2, 1)
     world, rank, _ = setup_dist(args)
     wl = Workload(args, rank)
-    wall, dev_ms, mode = timed_region(wl, args, world)
+    wall, dev_ms, mode, rep = timed_region(wl, args, world)
     K = args.steps
     units = wl.units_per_step * K * world
     value = units / wall
+    desc, units_per_step = wl.desc, wl.units_per_step
+    pol = policy_block(wl, args, wall / K, args.workload) if args.workload in ("rollout", "train") else None
+    del wl
+    torch.cuda.empty_cache()
+    train = None
+    if world > 1 and args.workload == "env" and not args.no_extras:
+        train = train_leg(args, rank, world)                      # every rank: it contains the collective
     if rank != 0:
         return
     per_launch_s = dev_ms * 1e-3 / K
-    alg_bytes = ALG_BYTES[args.workload] * wl.units_per_step
+    alg_bytes = ALG_BYTES[args.workload] * units_per_step
     achieved = alg_bytes / per_launch_s / 1e9
     traffic, valu = None, None
     tpath = os.path.join(REPO, "profiles", "traffic.json")           # PMC-derived HBM bytes per launch, if collected
@@ -367,6 +547,8 @@ def main():
         tj = json.load(open(tpath))
         traffic = tj.get(f"{args.workload}_{args.precision}_{args.batch}")
         valu = tj.get(f"{args.workload}_{args.precision}_{args.batch}_valu")      # VALU-pipe occupancy from the same PMC runs
+    tflops = ALG_FLOPS[args.workload] * units_per_step / per_launch_s / 1e12
+    valu_bound = args.workload in ("env", "env_pid", "rollout", "train") or (args.workload == "physics" and args.physics_substeps > 1)
     out = {
         "metric": "env-steps/sec (whole node), rate-control task, batch 65536 per GPU" if args.workload.startswith("env")
                   else f"{args.workload} {'env' if args.workload in ('rollout', 'train') else 'aircraft'}-steps/sec",
@@ -375,23 +557,27 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"f64": "f64", "mixed": "f32 compute / f64 state", "f32": "f32"}[args.precision],
         "data": "synthetic",
-        "config": {"workload": wl.desc, "precision": args.precision, "batch_per_gpu": args.batch,
+        "repeats": rep["repeats"], "region_wall_s": {"median": wall, "min": rep["wall_min_s"], "max": rep["wall_max_s"]},
+        "config": {"workload": desc, "precision": args.precision, "batch_per_gpu": args.batch,
                    "launch": mode, "parallelism": f"{world} independent env shards, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
                      "kernel_ms": per_launch_s * 1e3,
-                     "note": "kernel is vector-ALU bound (AI ~ 133 flop/B); see compute"},
-        "compute": {"achieved_tflops": ALG_FLOPS[args.workload] * wl.units_per_step / per_launch_s / 1e12,
-                    "peak_tflops": FP32_VECTOR_PEAK_TFLOPS,
-                    "frac": ALG_FLOPS[args.workload] * wl.units_per_step / per_launch_s / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
-                    "valu_pmc": valu},
+                     "binding": "valu" if valu_bound else "hbm",
+                     "valu": {"achieved": tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": tflops / FP32_VECTOR_PEAK_TFLOPS,
+                              "flops_per_unit": ALG_FLOPS[args.workload]},
+                     "note": ("the fused env step is vector-ALU bound (AI ~ 133 flop/B): `frac` is the HBM fraction the "
+                              "north-star asks for, `valu.frac` is the binding roof") if valu_bound else
+                             "HBM-bound launch; valu.frac reported beside it"},
+        "compute": {"achieved_tflops": tflops, "peak_tflops": FP32_VECTOR_PEAK_TFLOPS,
+                    "frac": tflops / FP32_VECTOR_PEAK_TFLOPS, "valu_pmc": valu},
     }
-    if args.workload in ("rollout", "train"):
-        mult = 1.0 if args.workload == "rollout" else (1.0 + 3.0 * args.ppo_epochs)      # fwd, or fwd + epochs x (fwd+bwd)
-        pf = wl.policy_flops * mult * wl.units_per_step / (wall / K) / 1e12
-        out["policy"] = {"flops_per_env_step_fwd": wl.policy_flops, "achieved_tflops": pf, "dtype": args.policy_dtype,
-                         "peak_tflops_dense": 2500.0 if args.policy_dtype == "bf16" else 157.3,
-                         "frac": pf / (2500.0 if args.policy_dtype == "bf16" else 157.3)}
+    if pol is not None:
+        out["policy"] = pol
+    if train is not None:
+        out["train"] = train
     if world == 1 and args.workload == "env" and not args.no_extras:
         out["extras"] = extras(args)
     if world == 1 and not args.no_cpu_baseline:

@@ -23,7 +23,7 @@ SIGNATURES = {
     "fdyn_abi_version": (_i, []),
     "fdyn_num_substeps": (_i, [_d, _d]),
     "fdyn_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
-    "fdyn_set_lanes_per_wave": (_i, [_i]),
+    "fdyn_event_capacity": (_i64, [_i64]),
     "fdyn_sixdof_step_f64": (_i, _SIXDOF), "fdyn_sixdof_step_mixed": (_i, _SIXDOF), "fdyn_sixdof_step_f32": (_i, _SIXDOF),
     "fdyn_derived_f64": (_i, [_p, _i64, _p, _p]), "fdyn_derived_f32": (_i, [_p, _i64, _p, _p]),
     "fdyn_pid_compute_batch": (_i, [_p, _i, _p, _p, _p, _f, _p, _i64, _p]),

@@ -62,14 +62,45 @@ FD_DEV void sincos(float x, float& s, float& c)
     s = (q & 2) ? -ss : ss;
     c = ((q + 1) & 2) ? -cc : cc;
 }
-// v_sin_f32 / v_cos_f32 (argument in revolutions): 3 instructions instead of ~26, but ~4x the drift of the software
-// version (measured: the mixed variant leaves the 1e-4 gate, 1.8e-4 on the dt = 10 ms fixture).  Used only by the pure
-// fp32 throughput variant, which is outside the gate anyway.
-FD_DEV void sincos_hw(float x, float& s, float& c)
+// rotate (s, c) = (sin a, cos a) by a SMALL angle d (|d| <= 0.125): sin/cos of d from their Taylor series (truncation
+// d^7/5040 < 1e-10, d^6/720 < 6e-9 -- below the fp32 ulp of the result), 10 VALU instead of a 25-instruction sincos.
+// The RK4 stage states differ from the step's initial state by (dt/2 or dt) * euler rate, and consecutive sub-steps by
+// dt/6 * (k1 + 2 k2 + 2 k3 + k4): all the trigonometry of a sub-step comes from ONE sincos per angle per launch.
+FD_DEV void rotate_small(float s, float c, float d, float& so, float& co)
 {
-    const float rev = x * 0.15915494309189535f;
-    s = __builtin_amdgcn_sinf(rev);
-    c = __builtin_amdgcn_cosf(rev);
+    const float z = d * d;
+    const float cd = __builtin_fmaf(z, __builtin_fmaf(z, 4.1666667908e-2f, -0.5f), 1.0f);
+    const float sd = __builtin_fmaf(z * __builtin_fmaf(z, 8.3333337680e-3f, -1.6666667163e-1f), d, d);
+    so = __builtin_fmaf(s, cd, c * sd);
+    co = __builtin_fmaf(c, cd, -(s * sd));
+}
+// atan(t) for |t| <= 0.7 with NO range reduction: t + t z P(z), z = t^2, degree-5 weighted least-squares fit on Chebyshev
+// nodes (max abs error 4.7e-8 in fp32 evaluation; scripts in DESIGN.md §4).  0.7 = tan(35 deg) covers the angle-of-attack
+// clip of every shipped aircraft type (30 deg), so alpha never needs the three-range atan2 in flight.
+#define FD_ATAN_WIDE_LIMIT 0.7f
+FD_DEV float atan_wide(float t)
+{
+    const float z = t * t;
+    float p = __builtin_fmaf(z, 2.0541535690e-02f, -6.1546623707e-02f);
+    p = __builtin_fmaf(z, p, 1.0221967846e-01f);
+    p = __builtin_fmaf(z, p, -1.4136675000e-01f);
+    p = __builtin_fmaf(z, p, 1.9987617433e-01f);
+    p = __builtin_fmaf(z, p, -3.3332955837e-01f);
+    return __builtin_fmaf(p * z, t, t);
+}
+// asin(x) for |x| <= 0.75: x + x z P(z), degree-7 fit of the same kind (max abs error 5.1e-8)
+#define FD_ASIN_WIDE_LIMIT 0.75f
+FD_DEV float asin_wide(float x)
+{
+    const float z = x * x;
+    float p = __builtin_fmaf(z, 2.1202674508e-01f, -3.1944271922e-01f);
+    p = __builtin_fmaf(z, p, 2.6334178448e-01f);
+    p = __builtin_fmaf(z, p, -7.6388612390e-02f);
+    p = __builtin_fmaf(z, p, 5.3024884313e-02f);
+    p = __builtin_fmaf(z, p, 4.1755288839e-02f);
+    p = __builtin_fmaf(z, p, 7.5183674693e-02f);
+    p = __builtin_fmaf(z, p, 1.6666238010e-01f);
+    return __builtin_fmaf(p * z, x, x);
 }
 FD_DEV float atan_pos(float a)
 {   // atan for a >= 0 (Cephes atanf: two range reductions + degree-4 polynomial in a^2), branch-free
@@ -93,6 +124,25 @@ FD_DEV float atan2(float y, float x)
     a = (ay > ax) ? 1.5707963267948966f - a : a;
     a = (x < 0.0f) ? 3.14159265358979323846f - a : a;
     return __builtin_copysignf(a, y);
+}
+FD_DEV float asin_poly(float zz)
+{   // (asin(t) - t) / t^3 on t^2 = zz <= 0.25 (Cephes asinf coefficients)
+    float p = __builtin_fmaf(zz, 4.2163199048e-2f, 2.4181311049e-2f);
+    p = __builtin_fmaf(zz, p, 4.5470025998e-2f);
+    p = __builtin_fmaf(zz, p, 7.4953002686e-2f);
+    return __builtin_fmaf(zz, p, 1.6666752422e-1f);
+}
+FD_DEV float asin_small(float x)                    // |x| <= 0.5 (beyond it the caller takes asin_from_one_minus)
+{
+    const float zz = x * x;
+    return __builtin_fmaf(asin_poly(zz) * zz, x, x);
+}
+FD_DEV float asin_from_one_minus(float om)          // asin(1 - om) for om in [0, 0.5]: pi/2 - 2 asin(sqrt(om / 2))
+{
+    const float zz = 0.5f * om;
+    const float t = sqrt(zz);
+    const float r = __builtin_fmaf(asin_poly(zz) * zz, t, t);
+    return __builtin_fmaf(-2.0f, r, 1.5707963267948966f);
 }
 FD_DEV float asin(float x)
 {   // Cephes asinf: |x| > 0.5 -> pi/2 - 2 asin(sqrt((1-|x|)/2))
@@ -161,11 +211,13 @@ template <typename T> struct Params {
     T min_airspeed, min_u, max_de, max_da, max_dr, thrust_zero_v;
     T max_alpha, max_pitch, max_acc, max_ang_acc;
     T inv_ixx, inv_iyy, inv_izz, sin_max_alpha, cos_max_alpha;
+    T half_b, half_c, inv_thrust_zero_v, izz_m_iyy, ixx_m_izz, iyy_m_ixx, half_rho_S, tan_alpha_fast, alpha_needs_atan2,
+      sin_max_pitch, cos_max_pitch;   // fp32 evaluation only
 
     // `blk` points at one FD_NP-word block staged in LDS (stored as double; narrowed here once per launch)
     FD_DEV void load(const double* blk)
     {
-        mass = T(blk[FD_P_MASS]); inv_mass = T(1.0) / mass;                     // simplified_6dof.py:455
+        mass = T(blk[FD_P_MASS]); inv_mass = T(blk[FD_PD_INV_MASS]);            // simplified_6dof.py:455
         ixx = T(blk[FD_P_IXX]); iyy = T(blk[FD_P_IYY]); izz = T(blk[FD_P_IZZ]);
         S = T(blk[FD_P_WING_AREA]); b = T(blk[FD_P_WING_SPAN]); c = T(blk[FD_P_CHORD]);
         cl_0 = T(blk[FD_P_CL_0]); cl_alpha = T(blk[FD_P_CL_ALPHA]); cd_0 = T(blk[FD_P_CD_0]);
@@ -180,8 +232,43 @@ template <typename T> struct Params {
         max_dr = T(blk[FD_P_MAX_RUDDER_RAD]); thrust_zero_v = T(blk[FD_P_THRUST_ZERO_VELOCITY]);
         max_alpha = T(blk[FD_P_MAX_ALPHA_RAD]); max_pitch = T(blk[FD_P_MAX_PITCH_RAD]);
         max_acc = T(blk[FD_P_MAX_ACCELERATION]); max_ang_acc = T(blk[FD_P_MAX_ANGULAR_ACCELERATION]);
-        inv_ixx = T(1) / ixx; inv_iyy = T(1) / iyy; inv_izz = T(1) / izz;     // used by the fp32 variants only
-        sin_max_alpha = T(::sin(blk[FD_P_MAX_ALPHA_RAD])); cos_max_alpha = T(::cos(blk[FD_P_MAX_ALPHA_RAD]));
+        inv_ixx = T(blk[FD_PD_INV_IXX]); inv_iyy = T(blk[FD_PD_INV_IYY]); inv_izz = T(blk[FD_PD_INV_IZZ]);   // fp32 variants only
+        sin_max_alpha = T(blk[FD_PD_SIN_MAX_ALPHA]); cos_max_alpha = T(blk[FD_PD_COS_MAX_ALPHA]);
+        half_b = T(0.5) * b; half_c = T(0.5) * c; inv_thrust_zero_v = T(blk[FD_PD_INV_THRUST_ZERO_V]);
+        izz_m_iyy = izz - iyy; ixx_m_izz = ixx - izz; iyy_m_ixx = iyy - ixx;
+        half_rho_S = half_rho * S; tan_alpha_fast = T(blk[FD_PD_TAN_ALPHA_FAST]);
+        alpha_needs_atan2 = T(blk[FD_PD_ALPHA_NEEDS_ATAN2]);
+        sin_max_pitch = T(blk[FD_PD_SIN_MAX_PITCH]); cos_max_pitch = T(blk[FD_PD_COS_MAX_PITCH]);
+    }
+    // The derived words exist only in the STAGED (LDS) copy of a parameter block (stride FD_NP_STAGED): the first
+    // FD_ND_LANES threads of a workgroup fill them while the block is staged (fdyn_kernels.hip: stage_params), one word per
+    // lane, instead of every lane of every launch running fp64 ocml sin/cos and divisions before it can start (~400 VALU
+    // of a 1600-VALU one-step launch).  Callers of the C-ABI never see them: params stays [n_types][FD_NP].
+    //   lanes 0..4 : reciprocals (fp64 division: inv_mass is used by the fp64 parity path too)
+    //   lanes 5..6 : sin / cos of the alpha limit and of the pitch limit (fp64 ocml: the f64 variant never reads them, but
+    //                the fp32 variants' clip cases should not depend on a second sincos implementation)
+    static constexpr int FD_ND_LANES = 7;
+    static FD_DEV void derive_lane(int lane, const double* __restrict__ src, double* blk)
+    {
+        if (lane < 5) {
+            const int from = lane == 0 ? FD_P_MASS : (lane == 1 ? FD_P_IXX : (lane == 2 ? FD_P_IYY : (lane == 3 ? FD_P_IZZ : FD_P_THRUST_ZERO_VELOCITY)));
+            const int to = lane == 0 ? FD_PD_INV_MASS : (lane == 1 ? FD_PD_INV_IXX : (lane == 2 ? FD_PD_INV_IYY : (lane == 3 ? FD_PD_INV_IZZ : FD_PD_INV_THRUST_ZERO_V)));
+            blk[to] = 1.0 / src[from];
+        } else if (lane < FD_ND_LANES) {
+            const bool is_alpha = lane == 5;
+            const double a = src[is_alpha ? FD_P_MAX_ALPHA_RAD : FD_P_MAX_PITCH_RAD];
+            double sn, cs;
+            ::sincos(a, &sn, &cs);
+            blk[is_alpha ? FD_PD_SIN_MAX_ALPHA : FD_PD_SIN_MAX_PITCH] = sn;
+            blk[is_alpha ? FD_PD_COS_MAX_ALPHA : FD_PD_COS_MAX_PITCH] = cs;
+            if (is_alpha) {
+                // |w| <= tan(max_alpha) u_safe <=> the alpha clip is inactive; the polynomial serves it while tan <= 0.7
+                const double tl = sn / cs;
+                const bool poly_ok = a > 0.0 && a < 1.5 && tl <= double(FD_ATAN_WIDE_LIMIT);
+                blk[FD_PD_TAN_ALPHA_FAST] = poly_ok ? tl : 0.0;
+                blk[FD_PD_ALPHA_NEEDS_ATAN2] = poly_ok ? 0.0 : 1.0;
+            }
+        }
     }
 };
 
@@ -198,54 +285,48 @@ template <typename S> struct Limits {
 // controls after set_controls' clip (simplified_6dof.py:221-226), pre-multiplied into radians per launch
 template <typename T> struct Controls {
     T de_rad, da_rad, dr_rad, throttle;
+    // fp32 evaluation only: the control-dependent terms of the coefficient build-up, constant over a launch's sub-steps
+    T cl0_de, cm_de, cl_da, cn_dr, cy, thrust_max;
     template <typename S> FD_DEV void set(const Params<T>& P, S elevator, S aileron, S rudder, S thr)
     {
         de_rad = T(clipv<S>(elevator, S(-1), S(1))) * P.max_de;     // :383
         da_rad = T(clipv<S>(aileron, S(-1), S(1))) * P.max_da;      // :415
         dr_rad = T(clipv<S>(rudder, S(-1), S(1))) * P.max_dr;       // :389
         throttle = T(clipv<S>(thr, S(0), S(1)));
+        if constexpr (sizeof(T) == 4) {
+            cl0_de = P.cl_0 + P.cl_de * de_rad;                     // :384   CL = cl0 + cl_alpha alpha + cl_de de
+            cm_de = P.cm_de * de_rad;                               // :424
+            cl_da = P.cl_da * da_rad;                               // :419
+            cn_dr = P.cn_dr * dr_rad;                               // :431
+            cy = P.cy_dr * dr_rad;                                  // :390
+            thrust_max = P.max_thrust * throttle;                   // :404
+        }
     }
 };
 
 // ----- one evaluation of the equations of motion: simplified_6dof.py:333-503 ----------------------------
-template <typename T, bool HW_TRIG = false>
+// The fp64 parity form: the reference's operation order, every clamp and guard where the reference has it.
+// (The fp32-evaluation variants use dynamics_fast below.)
+template <typename T>
 FD_DEV void dynamics(const Params<T>& P, const Controls<T>& C, const T (&x)[FD_NX], T (&xd)[FD_NX])
 {
+    static_assert(sizeof(T) == 8, "fp32 evaluation goes through dynamics_fast");
     const T u = x[3], v = x[4], w = x[5], theta = x[7];
     const T p = x[9], q = x[10], r = x[11];
     T sin_phi, cos_phi, sin_theta, cos_theta, sin_psi, cos_psi;
-    if constexpr (HW_TRIG) {
-        fast::sincos_hw(x[6], sin_phi, cos_phi);
-        fast::sincos_hw(theta, sin_theta, cos_theta);
-        fast::sincos_hw(x[8], sin_psi, cos_psi);
-    } else {
-        M<T>::sincos(x[6], sin_phi, cos_phi);
-        M<T>::sincos(theta, sin_theta, cos_theta);
-        M<T>::sincos(x[8], sin_psi, cos_psi);
-    }
+    M<T>::sincos(x[6], sin_phi, cos_phi);
+    M<T>::sincos(theta, sin_theta, cos_theta);
+    M<T>::sincos(x[8], sin_psi, cos_psi);
 
     const T airspeed = M<T>::sqrt(u * u + v * v + w * w);                               // :363
-    const T safe_airspeed = maxf(airspeed, P.min_airspeed);                             // :364
+    const T safe_airspeed = pymax(airspeed, P.min_airspeed);                            // :364
     const T au = M<T>::abs(u);
-    T u_safe;                                                                           // :368
-    if constexpr (sizeof(T) == 8) u_safe = au > T(1e-6) ? pymax(au, P.min_u) * signv(u) : P.min_u;
-    else u_safe = au > T(1e-6) ? __builtin_copysignf(__builtin_fmaxf(au, P.min_u), u) : P.min_u;
+    const T u_safe = au > T(1e-6) ? pymax(au, P.min_u) * signv(u) : P.min_u;            // :368
     T alpha = M<T>::atan2(w, u_safe);
+    alpha = clipv(alpha, -P.max_alpha, P.max_alpha);                                    // :370
     T sin_alpha, cos_alpha;
-    if constexpr (sizeof(T) == 8) {
-        alpha = clipv(alpha, -P.max_alpha, P.max_alpha);                                // :370
-        M<T>::sincos(alpha, sin_alpha, cos_alpha);
-    } else {
-        // sin/cos of the UNCLIPPED alpha are w/h and u_safe/h (h = hypot): one v_rsq instead of a sincos; the clipped
-        // cases take the pre-computed sin/cos of +-max_alpha
-        const T inv_h = fast::rsq(u_safe * u_safe + w * w);
-        const bool hi = alpha > P.max_alpha, lo = alpha < -P.max_alpha;
-        sin_alpha = hi ? P.sin_max_alpha : (lo ? -P.sin_max_alpha : w * inv_h);
-        cos_alpha = (hi || lo) ? P.cos_max_alpha : u_safe * inv_h;
-        alpha = clipf(alpha, -P.max_alpha, P.max_alpha);
-    }
-    const T inv_V = fdiv(T(1), safe_airspeed);                                          // fp32 only: one v_rcp, reused
-    const T beta = M<T>::asin(clipf(sizeof(T) == 8 ? v / safe_airspeed : v * inv_V, T(-1), T(1)));                   // :376
+    M<T>::sincos(alpha, sin_alpha, cos_alpha);
+    const T beta = M<T>::asin(clipv(v / safe_airspeed, T(-1), T(1)));                   // :376
     const T q_dyn = P.half_rho * (airspeed * airspeed);                                 // :379 (unclamped V)
 
     const T cl = P.cl_0 + P.cl_alpha * alpha + P.cl_de * C.de_rad;                      // :384-390
@@ -256,21 +337,15 @@ FD_DEV void dynamics(const Params<T>& P, const Controls<T>& C, const T (&x)[FD_N
     const T fx_aero = -drag * cos_alpha + lift * sin_alpha;                             // :397-399
     const T fz_aero = -drag * sin_alpha - lift * cos_alpha;
 
-    const T thrust_factor = maxf(T(0), T(1) - fdiv(airspeed, P.thrust_zero_v));             // :403
+    const T thrust_factor = pymax(T(0), T(1) - airspeed / P.thrust_zero_v);             // :403
     const T thrust = P.max_thrust * C.throttle * thrust_factor;
 
     const T fx = fx_aero + thrust + (-P.g * sin_theta) * P.mass;                        // :409-411
     const T fy = side_force + (P.g * cos_theta * sin_phi) * P.mass;
     const T fz = fz_aero + (P.g * cos_theta * cos_phi) * P.mass;
 
-    T half_span_over_V, half_chord_over_V;                                              // :416-417
-    if constexpr (sizeof(T) == 8) {
-        half_span_over_V = P.b / (T(2) * safe_airspeed);
-        half_chord_over_V = P.c / (T(2) * safe_airspeed);
-    } else {
-        half_span_over_V = (T(0.5) * P.b) * inv_V;
-        half_chord_over_V = (T(0.5) * P.c) * inv_V;
-    }
+    const T half_span_over_V = P.b / (T(2) * safe_airspeed);                            // :416-417
+    const T half_chord_over_V = P.c / (T(2) * safe_airspeed);
     const T l_moment = q_S * P.b * (P.cl_da * C.da_rad + P.damp_roll * p * half_span_over_V + P.cl_beta * beta);
     const T m_moment = q_S * P.c * (P.cm_de * C.de_rad + P.cm_alpha * alpha + P.damp_pitch * q * half_chord_over_V);
     const T n_moment = q_S * P.b * (P.cn_dr * C.dr_rad + P.damp_yaw * r * half_span_over_V + P.cn_beta * beta);
@@ -284,66 +359,172 @@ FD_DEV void dynamics(const Params<T>& P, const Controls<T>& C, const T (&x)[FD_N
     xd[4] = fy * P.inv_mass - r * u + p * w;
     xd[5] = fz * P.inv_mass - p * v + q * u;
 
-    const T theta_safe = clipf(theta, -P.max_pitch, P.max_pitch);                       // :463-471
-    T cos_ts, tan_ts;
-    if constexpr (sizeof(T) == 8) {
-        cos_ts = (theta_safe == theta) ? cos_theta : M<T>::cos(theta_safe);
-        tan_ts = M<T>::tan(theta_safe);
-        xd[8] = (sin_phi * q + cos_phi * r) / cos_ts;
-    } else {
-        T sin_ts = sin_theta;
-        cos_ts = cos_theta;
-        if (theta_safe != theta) M<T>::sincos(theta_safe, sin_ts, cos_ts);             // rare: RK4 stage beyond +-85 deg
-        const T inv_c = fast::rcp(cos_ts);
-        tan_ts = sin_ts * inv_c;
-        xd[8] = (sin_phi * q + cos_phi * r) * inv_c;
-    }
+    const T theta_safe = clipv(theta, -P.max_pitch, P.max_pitch);                       // :463-471
+    const T cos_ts = (theta_safe == theta) ? cos_theta : M<T>::cos(theta_safe);
+    const T tan_ts = M<T>::tan(theta_safe);
+    xd[8] = (sin_phi * q + cos_phi * r) / cos_ts;
     xd[6] = p + sin_phi * tan_ts * q + cos_phi * tan_ts * r;
     xd[7] = cos_phi * q - sin_phi * r;
 
-    if constexpr (sizeof(T) == 8) {                                                     // :474-482
-        xd[9] = (l_moment - (P.izz - P.iyy) * q * r) / P.ixx;
-        xd[10] = (m_moment - (P.ixx - P.izz) * p * r) / P.iyy;
-        xd[11] = (n_moment - (P.iyy - P.ixx) * p * q) / P.izz;
-    } else {
-        xd[9] = (l_moment - (P.izz - P.iyy) * q * r) * P.inv_ixx;
-        xd[10] = (m_moment - (P.ixx - P.izz) * p * r) * P.inv_iyy;
-        xd[11] = (n_moment - (P.iyy - P.ixx) * p * q) * P.inv_izz;
-    }
+    xd[9] = (l_moment - (P.izz - P.iyy) * q * r) / P.ixx;                               // :474-482
+    xd[10] = (m_moment - (P.ixx - P.izz) * p * r) / P.iyy;
+    xd[11] = (n_moment - (P.iyy - P.ixx) * p * q) / P.izz;
 
-    if constexpr (sizeof(T) == 8) {
 #pragma unroll
-        for (int i = 9; i < 12; ++i) xd[i] = clipv(xd[i], -P.max_ang_acc, P.max_ang_acc);  // :485-490
+    for (int i = 9; i < 12; ++i) xd[i] = clipv(xd[i], -P.max_ang_acc, P.max_ang_acc);  // :485-490
 #pragma unroll
-        for (int i = 3; i < 6; ++i) xd[i] = clipv(xd[i], -P.max_acc, P.max_acc);
-        // :496-501 non-finite derivatives -> 0.  Every derivative is bounded (clamped or O(100)), so their sum is
-        // finite iff each one is: one class test on the sum guards a rare, wave-uniformly-skipped fix-up branch.
-        T acc = xd[0];
+    for (int i = 3; i < 6; ++i) xd[i] = clipv(xd[i], -P.max_acc, P.max_acc);
+    // :496-501 non-finite derivatives -> 0.  Every derivative is bounded (clamped or O(100)), so their sum is
+    // finite iff each one is: one class test on the sum guards a rare, wave-uniformly-skipped fix-up branch.
+    T acc = xd[0];
 #pragma unroll
-        for (int i = 1; i < 12; ++i) acc += xd[i];
-        if (!M<T>::finite(acc)) {
+    for (int i = 1; i < 12; ++i) acc += xd[i];
+    if (!M<T>::finite(acc)) {
 #pragma unroll
-            for (int i = 0; i < 12; ++i) xd[i] = M<T>::finite(xd[i]) ? xd[i] : T(0);
-        }
-    } else {
-        // fp32: guard first (NaN -> 0 like :496-501; an infinity is left for the clamp, which the reference also applies
-        // before its finiteness test), then one v_med3_f32 per clamped derivative.
-        T acc = xd[0];
-#pragma unroll
-        for (int i = 1; i < 12; ++i) acc += xd[i];
-        if (!M<T>::finite(acc)) {
-#pragma unroll
-            for (int i = 0; i < 12; ++i) xd[i] = (xd[i] != xd[i]) ? T(0) : xd[i];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) xd[i] = M<T>::finite(xd[i]) ? xd[i] : T(0);
-#pragma unroll
-            for (int i = 6; i < 9; ++i) xd[i] = M<T>::finite(xd[i]) ? xd[i] : T(0);
-        }
-#pragma unroll
-        for (int i = 9; i < 12; ++i) xd[i] = clipf(xd[i], -P.max_ang_acc, P.max_ang_acc);
-#pragma unroll
-        for (int i = 3; i < 6; ++i) xd[i] = clipf(xd[i], -P.max_acc, P.max_acc);
+        for (int i = 0; i < 12; ++i) xd[i] = M<T>::finite(xd[i]) ? xd[i] : T(0);
     }
+}
+
+// ----- the same equations for the fp32-evaluation variants ("mixed", "f32"), written for instruction count -----------
+// Differences from dynamics<double> (all mathematically neutral; rounding differs at the fp32 ulp level):
+//   * sin / cos of the three Euler angles are INPUTS (Trig): the caller carries them and rotates them by the small
+//     stage / step increments (fast::rotate_small) instead of evaluating 12 sincos per RK4 step;
+//   * north / east rates as Rz(psi) applied to the yaw-free horizontal velocity (9 products instead of 18);
+//   * accelerations formed as (aero + thrust) / m + g-terms directly (no multiply by mass and divide again);
+//   * control-dependent coefficient terms pre-multiplied per launch (Controls);
+//   * the u_safe / alpha-clip / clamped-pitch guards of :364-376,463-471 are a handful of selects on staged constants
+//     (sin / cos of the alpha and pitch limits), alpha and beta come from wide no-range-reduction polynomials, and ONE
+//     wave-uniformly skipped block holds what is left (side-slip beyond 48 deg, Euler increments too large for the rotation
+//     series).  Measured on the bench's random-action fleet: 1.7 % of lane-steps leave the envelope of a
+//     narrower first version (|alpha| < 22 deg, |beta| < 30 deg), which put 65 % of the WAVES through its slow block;
+//   * no per-evaluation NaN guard: with a finite state every term is finite (divisors are clamped away from 0:
+//     V >= min_airspeed, |u_safe| >= min_u, |cos theta_safe| >= cos(max_pitch)), and the state is re-checked after every
+//     step by rk4_substeps' combined predicate -- the reference's guard (:496-501) can only fire on a non-finite state,
+//     which its own step() (:286-291) never leaves behind either.
+struct Trig { float sphi, cphi, sth, cth, spsi, cpsi; };
+FD_DEV Trig trig_of(float phi, float theta, float psi)
+{
+    Trig t;
+    fast::sincos(phi, t.sphi, t.cphi); fast::sincos(theta, t.sth, t.cth); fast::sincos(psi, t.spsi, t.cpsi);
+    return t;
+}
+// rotate by (d_phi, d_theta, d_psi); returns max |d|: beyond 0.125 rad the series is not good enough and the next
+// dynamics_fast call re-evaluates the sincos in full (its `dmax` argument)
+FD_DEV float trig_rotate(const Trig& t0, float dphi, float dth, float dpsi, Trig& t)
+{
+    fast::rotate_small(t0.sphi, t0.cphi, dphi, t.sphi, t.cphi);
+    fast::rotate_small(t0.sth, t0.cth, dth, t.sth, t.cth);
+    fast::rotate_small(t0.spsi, t0.cpsi, dpsi, t.spsi, t.cpsi);
+    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(dphi), __builtin_fabsf(dth)), __builtin_fabsf(dpsi));
+}
+
+#define FD_UNLIKELY(c) __builtin_expect(!!(c), 0)
+
+// x: the 12 state words (x[0..2] unread; x[6], x[8] read only when the trigonometry has to be rebuilt); tg is updated in
+// place when it is rebuilt, so a carried Trig stays repaired.
+FD_DEV void dynamics_fast(const Params<float>& P, const Controls<float>& C, const float (&x)[FD_NX], Trig& tg, float dmax,
+                          float (&xd)[FD_NX])
+{
+    const float u = x[3], v = x[4], w = x[5], theta = x[7];
+    const float p = x[9], q = x[10], r = x[11];
+
+    const float uw2 = __builtin_fmaf(u, u, w * w);
+    const float V2 = __builtin_fmaf(v, v, uw2);
+    const float airspeed = fast::sqrt(V2);                                                  // :363
+    const float Vs = __builtin_fmaxf(airspeed, P.min_airspeed);                             // :364
+    const float inv_V = fast::rcp(Vs);
+
+    // ---- angle of attack :368-370, branch-free.  alpha only matters inside +-max_alpha: |w| <= tan(max_alpha) u_safe (which
+    // implies u_safe > 0) <=> the clip is inactive, and then |w / u_safe| <= 0.7 is inside the no-range-reduction
+    // polynomial; otherwise atan2(w, u_safe) lies beyond the limit on the side of sign(w) and clips to copysign(max_alpha, w)
+    // (u_safe < 0, w = +-0 included: atan2 = +-pi).  sin / cos of the UNCLIPPED alpha are w/h and u_safe/h.
+    const float au = __builtin_fabsf(u);
+    const float us = au > 1e-6f ? __builtin_copysignf(__builtin_fmaxf(au, P.min_u), u) : P.min_u;
+    const float inv_h = fast::rsq(__builtin_fmaf(us, us, w * w));                           // |u_safe| >= min_u > 0
+    const float t_alpha = w * fast::rcp(us);
+    const bool a_in = __builtin_fabsf(w) <= P.tan_alpha_fast * us;
+    const float alpha = a_in ? fast::atan_wide(t_alpha) : __builtin_copysignf(P.max_alpha, w);
+    const float sin_alpha = a_in ? w * inv_h : __builtin_copysignf(P.sin_max_alpha, w);
+    const float cos_alpha = a_in ? us * inv_h : P.cos_max_alpha;
+
+    // ---- side-slip :376, polynomial up to |v| / V = 0.75
+    float beta = fast::asin_wide(v * inv_V);
+
+    // ---- clamped pitch for the Euler rates :463: sin / cos of clip(theta) are the carried ones or those of +-max_pitch
+    const bool th_in = __builtin_fabsf(theta) <= P.max_pitch;
+    float sth_e = th_in ? tg.sth : __builtin_copysignf(P.sin_max_pitch, theta);
+    float cth_e = th_in ? tg.cth : P.cos_max_pitch;
+
+    // ---- the rare block (2-5 % of waves under random actions): side-slip beyond 48 deg, an Euler-angle increment too large
+    // for the rotation series, or an aircraft type whose alpha limit lies beyond the polynomial
+    const bool ordinary = (__builtin_fabsf(v) <= FD_ASIN_WIDE_LIMIT * Vs) & (dmax <= 0.125f) & (P.alpha_needs_atan2 == 0.0f);
+    float alpha_r = alpha, sin_alpha_r = sin_alpha, cos_alpha_r = cos_alpha;
+    if (FD_UNLIKELY(!ordinary)) {
+        if (!(dmax <= 0.125f)) {
+            tg = trig_of(x[6], theta, x[8]);
+            sth_e = th_in ? tg.sth : sth_e; cth_e = th_in ? tg.cth : cth_e;
+        }
+        if (P.alpha_needs_atan2 != 0.0f) {                  // max_alpha > 35 deg: the reference's own sequence
+            const float a_raw = fast::atan2(w, us);
+            const bool hi = a_raw > P.max_alpha, lo = a_raw < -P.max_alpha;
+            sin_alpha_r = hi ? P.sin_max_alpha : (lo ? -P.sin_max_alpha : w * inv_h);
+            cos_alpha_r = (hi || lo) ? P.cos_max_alpha : us * inv_h;
+            alpha_r = clipf(a_raw, -P.max_alpha, P.max_alpha);
+        }
+        // asin is ill-conditioned at +-1 (sideways flight: a tumbling aircraft at the rate clamp has |v| / V = 1 - 2e-8,
+        // which fp32 rounds to 1 and beta is off by 3e-4 rad -- measured as THE source of mixed-precision outliers over 4096
+        // aircraft): asin = pi/2 - 2 asin(sqrt((1 - |x|) / 2)) with 1 - |v|/V = (u^2 + w^2) / (V (V + |v|)), no cancellation
+        const float xb = clipf(v * inv_V, -1.0f, 1.0f);
+        if (__builtin_fabsf(xb) > FD_ASIN_WIDE_LIMIT) {
+            const float av = __builtin_fabsf(v);
+            const float one_minus = (airspeed >= P.min_airspeed) ? uw2 * fast::rcp(Vs * (Vs + av))
+                                                                 : __builtin_fmaxf(Vs - av, 0.0f) * inv_V;
+            beta = __builtin_copysignf(fast::asin_from_one_minus(one_minus), xb);
+        }
+    }
+    const float sphi = tg.sphi, cphi = tg.cphi, cpsi = tg.cpsi, spsi = tg.spsi, sth = tg.sth, cth = tg.cth;
+
+    const float q_S = P.half_rho_S * V2;                                                    // :379 (unclamped V)
+    const float cl = __builtin_fmaf(P.cl_alpha, alpha_r, C.cl0_de);                           // :384-390
+    const float cd = __builtin_fmaf(P.cd_alpha2, alpha_r * alpha_r, P.cd_0);
+    const float lift = q_S * cl, drag = q_S * cd;
+    const float fx_aero = __builtin_fmaf(lift, sin_alpha_r, -(drag * cos_alpha_r));             // :397-399
+    const float fz_aero = -__builtin_fmaf(lift, cos_alpha_r, drag * sin_alpha_r);
+    const float thrust = C.thrust_max * __builtin_fmaxf(0.0f, __builtin_fmaf(-airspeed, P.inv_thrust_zero_v, 1.0f));   // :403
+
+    // :409-411 + :455-460   a = F/m + g-terms - omega x v
+    xd[3] = __builtin_fmaf(fx_aero + thrust, P.inv_mass, __builtin_fmaf(r, v, __builtin_fmaf(-q, w, -(P.g * sth))));
+    xd[4] = __builtin_fmaf(q_S * C.cy, P.inv_mass, __builtin_fmaf(p, w, __builtin_fmaf(-r, u, P.g * (cth * sphi))));
+    xd[5] = __builtin_fmaf(fz_aero, P.inv_mass, __builtin_fmaf(q, u, __builtin_fmaf(-p, v, P.g * (cth * cphi))));
+
+    const float hsV = P.half_b * inv_V, hcV = P.half_c * inv_V;                             // :416-417
+    const float qSb = q_S * P.b;
+    const float l_moment = qSb * __builtin_fmaf(P.cl_beta, beta, __builtin_fmaf(P.damp_roll * p, hsV, C.cl_da));
+    const float m_moment = (q_S * P.c) * __builtin_fmaf(P.cm_alpha, alpha_r, __builtin_fmaf(P.damp_pitch * q, hcV, C.cm_de));
+    const float n_moment = qSb * __builtin_fmaf(P.cn_beta, beta, __builtin_fmaf(P.damp_yaw * r, hsV, C.cn_dr));
+    xd[9] = __builtin_fmaf(-P.izz_m_iyy * q, r, l_moment) * P.inv_ixx;                      // :474-482
+    xd[10] = __builtin_fmaf(-P.ixx_m_izz * p, r, m_moment) * P.inv_iyy;
+    xd[11] = __builtin_fmaf(-P.iyy_m_ixx * p, q, n_moment) * P.inv_izz;
+
+    // :440-452 NED rates: Rz(psi) * [ (cth u + sth (sphi v + cphi w)), (cphi v - sphi w) ],  down = cth (sphi v + cphi w) - sth u
+    const float sv_cw = __builtin_fmaf(sphi, v, cphi * w);
+    const float ah = __builtin_fmaf(cth, u, sth * sv_cw);
+    const float bh = __builtin_fmaf(cphi, v, -(sphi * w));
+    xd[0] = __builtin_fmaf(cpsi, ah, -(spsi * bh));
+    xd[1] = __builtin_fmaf(spsi, ah, cpsi * bh);
+    xd[2] = __builtin_fmaf(cth, sv_cw, -(sth * u));
+
+    // :463-471 Euler rates with the clamped pitch
+    const float inv_c = fast::rcp(cth_e);
+    const float qr = __builtin_fmaf(sphi, q, cphi * r);
+    xd[8] = qr * inv_c;
+    xd[6] = __builtin_fmaf(sth_e * inv_c, qr, p);
+    xd[7] = __builtin_fmaf(cphi, q, -(sphi * r));
+
+#pragma unroll
+    for (int i = 9; i < 12; ++i) xd[i] = clipf(xd[i], -P.max_ang_acc, P.max_ang_acc);      // :485-490
+#pragma unroll
+    for (int i = 3; i < 6; ++i) xd[i] = clipf(xd[i], -P.max_acc, P.max_acc);
 }
 
 // roll / yaw re-wrap of the stored state (simplified_6dof.py:266,270).  The f64 variant keeps the
@@ -420,26 +601,41 @@ FD_DEV void rk4_substeps(const Params<T>& P, const Limits<S>& Lm, const Controls
             post_step<S, T>(Lm, x);
         }
     } else {
-        constexpr bool HW = sizeof(S) == 4;                                  // pure-fp32 variant: hardware sin/cos
         const T hdt = T(S(0.5) * dt), fdt = T(dt), dt6 = T(dt / S(6));
         const T max_vel = T(Lm.max_vel), max_pitch = T(Lm.max_pitch), max_rate = T(Lm.max_rate);
         T x0[FD_NX];
 #pragma unroll
         for (int i = 0; i < 12; ++i) x0[i] = T(x[i]);
+        Trig t0 = trig_of(x0[6], x0[7], x0[8]);                  // the ONLY full sincos of the launch (rare blocks aside)
+        T d0 = T(0);                                             // max |increment| t0 was last rotated by
         for (int s = 0; s < n_sub; ++s) {
+            // position (0..2) feeds nothing back, and roll / yaw enter only through their sin / cos: the stage states
+            // carry velocity, angles (for the rare full rebuild and the +-85 deg guard) and rates; the trigonometry is rotated
             T xt[FD_NX], k[FD_NX], acc[FD_NX];
-            dynamics<T, HW>(P, C, x0, k);                                        // k1
+            Trig tt;
+            dynamics_fast(P, C, x0, t0, d0, k);                                  // k1
 #pragma unroll
-            for (int i = 0; i < 12; ++i) { acc[i] = k[i]; xt[i] = x0[i] + hdt * k[i]; }
-            dynamics<T, HW>(P, C, xt, k);                                        // k2
+            for (int i = 0; i < 12; ++i) acc[i] = k[i];
 #pragma unroll
-            for (int i = 0; i < 12; ++i) { acc[i] += T(2) * k[i]; xt[i] = x0[i] + hdt * k[i]; }
-            dynamics<T, HW>(P, C, xt, k);                                        // k3
+            for (int i = 3; i < 12; ++i) xt[i] = __builtin_fmaf(hdt, k[i], x0[i]);
+            T dm = trig_rotate(t0, hdt * k[6], hdt * k[7], hdt * k[8], tt);
+            dynamics_fast(P, C, xt, tt, dm, k);                                  // k2
 #pragma unroll
-            for (int i = 0; i < 12; ++i) { acc[i] += T(2) * k[i]; xt[i] = x0[i] + fdt * k[i]; }
-            dynamics<T, HW>(P, C, xt, k);                                        // k4
+            for (int i = 0; i < 12; ++i) acc[i] = __builtin_fmaf(T(2), k[i], acc[i]);
 #pragma unroll
-            for (int i = 0; i < 12; ++i) { x[i] += S(dt6 * (acc[i] + k[i])); x0[i] = T(x[i]); }
+            for (int i = 3; i < 12; ++i) xt[i] = __builtin_fmaf(hdt, k[i], x0[i]);
+            dm = trig_rotate(t0, hdt * k[6], hdt * k[7], hdt * k[8], tt);
+            dynamics_fast(P, C, xt, tt, dm, k);                                  // k3
+#pragma unroll
+            for (int i = 0; i < 12; ++i) acc[i] = __builtin_fmaf(T(2), k[i], acc[i]);
+#pragma unroll
+            for (int i = 3; i < 12; ++i) xt[i] = __builtin_fmaf(fdt, k[i], x0[i]);
+            dm = trig_rotate(t0, fdt * k[6], fdt * k[7], fdt * k[8], tt);
+            dynamics_fast(P, C, xt, tt, dm, k);                                  // k4
+            T inc[FD_NX];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { inc[i] = dt6 * (acc[i] + k[i]); x[i] += S(inc[i]); x0[i] = T(x[i]); }
+            d0 = trig_rotate(t0, inc[6], inc[7], inc[8], t0);
             // one predicate for every clamp / wrap / guard of :256-291, evaluated on the fp32 copy
             T sum = x0[0];
 #pragma unroll
@@ -449,10 +645,11 @@ FD_DEV void rk4_substeps(const Params<T>& P, const Limits<S>& Lm, const Controls
             const T amax = __builtin_fmaxf(__builtin_fabsf(x0[6]), __builtin_fabsf(x0[8]));
             const bool fix = !(vmax <= max_vel) | !(rmax <= max_rate) | !(__builtin_fabsf(x0[7]) <= max_pitch) |
                              !(amax <= T(FD_PI)) | (x0[2] > T(0)) | !M<T>::finite(sum);
-            if (fix) {
+            if (FD_UNLIKELY(fix)) {
                 post_step<S, T>(Lm, x);
 #pragma unroll
                 for (int i = 0; i < 12; ++i) x0[i] = T(x[i]);
+                d0 = T(1);                                       // the next k1 rebuilds the trigonometry in full
             }
         }
     }

@@ -32,22 +32,34 @@ __device__ __forceinline__ void stage(T* dst, const T* __restrict__ src, int n)
     for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
 }
 
-// Lane -> aircraft map with `lpw` (lanes per wave, 16/32/64) populated lanes per wave64.
-// Why: one lane = one aircraft gives N/64 waves; at the benchmark's N = 65 536 that is exactly ONE wave per SIMD, and a
-// lone wave issues at most one VALU instruction every ~4 cycles while the SIMD-32 retires a wave64 instruction in 2
-// (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost').  Populating only the low `lpw` lanes doubles (lpw = 32) the
-// number of waves for the same N, so each SIMD interleaves two independent instruction streams; the idle issue slots
-// it fills were being wasted anyway.  The host picks lpw from N (fdyn_pick_lpw); wave-level ops (ballot, the LDS
-// observation tile) only ever see the populated lanes.
+// Parameter blocks -> LDS: the FD_NP_USED caller words are copied; meanwhile FD_ND_LANES threads per aircraft type fill the
+// block's derived words (reciprocals, sin / cos of the alpha and pitch limits) straight from global memory, one word per
+// lane.  One barrier (the caller's).
+__device__ __forceinline__ void stage_params(double* s_params, const double* __restrict__ params, int n_types)
+{
+    for (int i = threadIdx.x; i < n_types * FD_NP_USED; i += blockDim.x) {
+        const int t = i / FD_NP_USED, k = i - t * FD_NP_USED;
+        s_params[t * FD_NP_STAGED + k] = params[t * FD_NP + k];
+    }
+    constexpr int NDL = Params<double>::FD_ND_LANES;
+    if (int(threadIdx.x) < n_types * NDL) {
+        const int t = threadIdx.x / NDL;
+        Params<double>::derive_lane(threadIdx.x - t * NDL, params + t * FD_NP, s_params + t * FD_NP_STAGED);
+    }
+}
+
+// Lane -> aircraft map: one lane = one aircraft, fully populated wave64.  (Round 1 measured half- and quarter-populated
+// waves -- 32 / 16 lanes per wave to get 2 / 4 waves per SIMD at N = 65 536: 67.8 -> 99.9 / 182.7 us for the mixed env
+// step.  The SIMD retires ~1 VALU per 5 cycles from one wave and ~1 per 3.4 from four, so doubling the instruction
+// count to double the wave count loses; the plumbing was removed in round 2, the result stays in DESIGN.md.)
 struct LaneMap { int64_t i, wave_first; int lane; bool on; };
-__device__ __forceinline__ LaneMap lane_map(int lpw, int64_t n)
+__device__ __forceinline__ LaneMap lane_map(int64_t n)
 {
     LaneMap m;
     m.lane = threadIdx.x & (FD_WAVE - 1);
-    const int64_t wave = (int64_t(blockIdx.x) * FD_BLOCK + threadIdx.x) >> 6;
-    m.wave_first = wave * lpw;
-    m.i = m.wave_first + m.lane;
-    m.on = (m.lane < lpw) && (m.i < n);
+    m.i = int64_t(blockIdx.x) * FD_BLOCK + threadIdx.x;
+    m.wave_first = m.i - m.lane;
+    m.on = m.i < n;
     return m;
 }
 
@@ -64,16 +76,16 @@ template <typename S, typename T>
 __global__ void __launch_bounds__(FD_BLOCK)
 sixdof_step_kernel(S* __restrict__ xs, const S* __restrict__ us, const uint8_t* __restrict__ type,
                    const double* __restrict__ params, int n_types, int64_t n, S dt_sub, int n_sub,
-                   S* __restrict__ derived_out, int lpw)
+                   S* __restrict__ derived_out)
 {
-    __shared__ double s_params[FD_MAX_TYPES * FD_NP];
-    stage(s_params, params, n_types * FD_NP);
+    __shared__ double s_params[FD_MAX_TYPES * FD_NP_STAGED];
+    stage_params(s_params, params, n_types);
     __syncthreads();
-    const LaneMap lm = lane_map(lpw, n);
+    const LaneMap lm = lane_map(n);
     const int64_t i = lm.i;
     if (!lm.on) return;
 
-    const double* blk = s_params + lane_type(type, i, n_types) * FD_NP;
+    const double* blk = s_params + lane_type(type, i, n_types) * FD_NP_STAGED;
     Params<T> P; P.load(blk);
     Limits<S> Lm; Lm.load(blk);
     S x[FD_NX];
@@ -140,23 +152,22 @@ cascade_step_kernel(S* __restrict__ xs, float* __restrict__ pid_state /*[9*3][n]
                     const uint8_t* __restrict__ type, const double* __restrict__ params, int n_types,
                     const float* __restrict__ pid_cfg /*[9][8]*/, const double* __restrict__ consts /*[FD_NC]*/,
                     const double* __restrict__ wps /*[n_wp][4]*/, int n_wp, int64_t n, S dt, int n_steps,
-                    S* __restrict__ surf_out /*[4][n] or null*/, int32_t* __restrict__ reached_total /*[n] or null*/,
-                    int lpw)
+                    S* __restrict__ surf_out /*[4][n] or null*/, int32_t* __restrict__ reached_total /*[n] or null*/)
 {
-    __shared__ double s_params[FD_MAX_TYPES * FD_NP];
+    __shared__ double s_params[FD_MAX_TYPES * FD_NP_STAGED];
     __shared__ float s_pid_cfg[FD_NPID * FD_NPC];
     __shared__ S s_consts[FD_NC];
     __shared__ S s_wps[FD_MAX_WAYPOINTS * FD_NWP];
-    stage(s_params, params, n_types * FD_NP);
+    stage_params(s_params, params, n_types);
     stage(s_pid_cfg, pid_cfg, FD_NPID * FD_NPC);
     for (int k = threadIdx.x; k < FD_NC; k += blockDim.x) s_consts[k] = S(consts[k]);
     for (int k = threadIdx.x; k < n_wp * FD_NWP; k += blockDim.x) s_wps[k] = S(wps[k]);
     __syncthreads();
-    const LaneMap lm = lane_map(lpw, n);
+    const LaneMap lm = lane_map(n);
     const int64_t i = lm.i;
     if (!lm.on) return;
 
-    const double* blk = s_params + lane_type(type, i, n_types) * FD_NP;
+    const double* blk = s_params + lane_type(type, i, n_types) * FD_NP_STAGED;
     Params<T> P; P.load(blk);
     Limits<S> Lm; Lm.load(blk);
     PidCfg cfg[FD_NPID];
@@ -214,19 +225,19 @@ __global__ void __launch_bounds__(FD_BLOCK)
 agent_step_kernel(int level, S* __restrict__ xs, float* __restrict__ pid_state /*[9*3][n]*/, const uint8_t* __restrict__ type,
                   const double* __restrict__ params, int n_types, const float* __restrict__ pid_cfg,
                   const double* __restrict__ consts, const S* __restrict__ cmd /*[4][n]*/, int64_t n, S dt, int n_steps,
-                  S* __restrict__ surf_out /*[4][n]*/, int lpw, int cfg_per_lane /*pid_cfg is [n][9][8]: one gain set per aircraft*/)
+                  S* __restrict__ surf_out /*[4][n]*/, int cfg_per_lane /*pid_cfg is [n][9][8]: one gain set per aircraft*/)
 {
-    __shared__ double s_params[FD_MAX_TYPES * FD_NP];
+    __shared__ double s_params[FD_MAX_TYPES * FD_NP_STAGED];
     __shared__ float s_pid_cfg[FD_NPID * FD_NPC];
     __shared__ S s_consts[FD_NC];
-    stage(s_params, params, n_types * FD_NP);
+    stage_params(s_params, params, n_types);
     if (!cfg_per_lane) stage(s_pid_cfg, pid_cfg, FD_NPID * FD_NPC);
     for (int k = threadIdx.x; k < FD_NC; k += blockDim.x) s_consts[k] = S(consts[k]);
     __syncthreads();
-    const LaneMap lm = lane_map(lpw, n);
+    const LaneMap lm = lane_map(n);
     const int64_t i = lm.i;
     if (!lm.on) return;
-    const double* blk = s_params + lane_type(type, i, n_types) * FD_NP;
+    const double* blk = s_params + lane_type(type, i, n_types) * FD_NP_STAGED;
     Params<T> P; P.load(blk);
     Limits<S> Lm; Lm.load(blk);
     PidCfg cfg[FD_NPID];
@@ -287,8 +298,10 @@ template <typename G> struct EnvConsts {
     __device__ __forceinline__ G max_rate(int ax) const { return mr0 * G(ax == 0) + mr1 * G(ax == 1) + mr2 * G(ax == 2); }
 };
 
+// `sched`: the four schedule words are live only for ramp / sine commands (rate_env.py:342-372); step and random-walk
+// fleets neither read nor write them (64 B per env per step at fp64) -- they stay 0, which is what reset leaves there
 template <typename G>
-__device__ __forceinline__ void env_load(EnvState<G>& e, const G* __restrict__ es, int64_t n, int64_t i)
+__device__ __forceinline__ void env_load(EnvState<G>& e, const G* __restrict__ es, int64_t n, int64_t i, bool sched = true)
 {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -297,12 +310,15 @@ __device__ __forceinline__ void env_load(EnvState<G>& e, const G* __restrict__ e
         e.sign_changes[k] = es[(FD_E_SIGN_P + k) * n + i];
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { e.prev_action[k] = es[(FD_E_PREV_AIL + k) * n + i]; e.sched[k] = es[(FD_E_SCHED0 + k) * n + i]; }
+    for (int k = 0; k < 4; ++k) {
+        e.prev_action[k] = es[(FD_E_PREV_AIL + k) * n + i];
+        e.sched[k] = sched ? es[(FD_E_SCHED0 + k) * n + i] : G(0);
+    }
     e.settle_timer = es[FD_E_SETTLE_TIMER * n + i]; e.is_settled = es[FD_E_IS_SETTLED * n + i];
     e.time = es[FD_E_TIME * n + i]; e.ep_return = es[FD_E_EP_RETURN * n + i];
 }
 template <typename G>
-__device__ __forceinline__ void env_store(const EnvState<G>& e, G* __restrict__ es, int64_t n, int64_t i)
+__device__ __forceinline__ void env_store(const EnvState<G>& e, G* __restrict__ es, int64_t n, int64_t i, bool sched = true)
 {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -311,7 +327,10 @@ __device__ __forceinline__ void env_store(const EnvState<G>& e, G* __restrict__ 
         es[(FD_E_SIGN_P + k) * n + i] = e.sign_changes[k];
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { es[(FD_E_PREV_AIL + k) * n + i] = e.prev_action[k]; es[(FD_E_SCHED0 + k) * n + i] = e.sched[k]; }
+    for (int k = 0; k < 4; ++k) {
+        es[(FD_E_PREV_AIL + k) * n + i] = e.prev_action[k];
+        if (sched) es[(FD_E_SCHED0 + k) * n + i] = e.sched[k];
+    }
     es[FD_E_SETTLE_TIMER * n + i] = e.settle_timer; es[FD_E_IS_SETTLED * n + i] = e.is_settled;
     es[FD_E_TIME * n + i] = e.time; es[FD_E_EP_RETURN * n + i] = e.ep_return;
 }
@@ -415,13 +434,13 @@ __device__ __forceinline__ void fetch_reset_record(const double* __restrict__ po
 
 // coalesced write-out of a wave's 64 x 18 observation tile through LDS (row stride 19 words: conflict-free)
 __device__ __forceinline__ void store_obs_tile(float* tile /*[64*19]*/, const float (&o)[FD_OBS_DIM], int lane,
-                                               float* __restrict__ obs_out, int64_t wave_first, int64_t n, int lpw)
+                                               float* __restrict__ obs_out, int64_t wave_first, int64_t n)
 {
 #pragma unroll
     for (int k = 0; k < FD_OBS_DIM; ++k) tile[lane * (FD_OBS_DIM + 1) + k] = o[k];
     __builtin_amdgcn_wave_barrier();
     int64_t valid = n - wave_first;
-    valid = valid < 0 ? 0 : (valid < lpw ? valid : lpw);
+    valid = valid < 0 ? 0 : (valid < FD_WAVE ? valid : FD_WAVE);
     float* dst = obs_out + wave_first * FD_OBS_DIM;
 #pragma unroll
     for (int k = 0; k < FD_OBS_DIM; ++k) {
@@ -436,10 +455,10 @@ template <typename S>
 __global__ void __launch_bounds__(FD_BLOCK)
 rate_env_reset_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict__ eis, float* __restrict__ pid_state,
                       const uint8_t* __restrict__ mask, const double* __restrict__ EC, const double* __restrict__ pool,
-                      int pool_depth, uint64_t seed, float* __restrict__ obs_out, int64_t n, int lpw)
+                      int pool_depth, uint64_t seed, float* __restrict__ obs_out, int64_t n)
 {
     __shared__ float s_tile[FD_BLOCK / FD_WAVE][FD_WAVE * (FD_OBS_DIM + 1)];
-    const LaneMap lm = lane_map(lpw, n);
+    const LaneMap lm = lane_map(n);
     const int64_t i = lm.i;
     const int lane = lm.lane, wave = threadIdx.x / FD_WAVE;
     const bool active = lm.on;
@@ -472,7 +491,7 @@ rate_env_reset_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restric
         airspeed_altitude<S>(x, airspeed, altitude);
         env_observation<S>(x, e, airspeed, altitude, o);
     }
-    store_obs_tile(s_tile[wave], o, lane, obs_out, lm.wave_first, n, lpw);
+    store_obs_tile(s_tile[wave], o, lane, obs_out, lm.wave_first, n);
 }
 
 // OCC2: cap the registers at 256 so that two waves fit per SIMD.  At exactly one wave per SIMD (65 536 envs on 256 CUs) the
@@ -491,13 +510,13 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
                      float* __restrict__ obs_out /*[n][18]*/, float* __restrict__ reward_f32, S* __restrict__ reward_full,
                      uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
                      int32_t* __restrict__ ev_count, int32_t* __restrict__ ev_count_next, int32_t* __restrict__ ev_int,
-                     float* __restrict__ ev_flt, int ev_cap, int64_t n, int lpw)
+                     float* __restrict__ ev_flt, int ev_cap, int64_t n)
 {
-    __shared__ double s_params[FD_MAX_TYPES * FD_NP];
+    __shared__ double s_params[FD_MAX_TYPES * FD_NP_STAGED];
     __shared__ float s_tile[FD_BLOCK / FD_WAVE][FD_WAVE * (FD_OBS_DIM + 1)];
     __shared__ float s_pid_cfg[3 * FD_NPC];
     __shared__ S s_consts[FD_NC];
-    stage(s_params, params, n_types * FD_NP);
+    stage_params(s_params, params, n_types);
     // actions == null: the fused rate-PID demonstrator drives the env.  residual_scale > 0 (with actions AND pid state):
     // ResidualRateControlEnv -- action = clip(PID + scale * residual) (residual_rate_env.py:99-157).
     const bool residual_mode = actions != nullptr && residual_scale > 0.0f && pid_state != nullptr;
@@ -508,15 +527,16 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
     }
     __syncthreads();
 
-    const LaneMap lm = lane_map(lpw, n);
+    const LaneMap lm = lane_map(n);
     const int64_t i = lm.i;
     const int lane = lm.lane, wave = threadIdx.x / FD_WAVE;
     const bool active = lm.on;
     EnvConsts<S> ec;
     load_env_consts<S>(EC, ec);
-    // double-buffered event counter: this launch appends to *ev_count and clears the OTHER slot for the next
+    const bool uses_sched = ec.cmd_type == FD_CMD_RAMP || ec.cmd_type == FD_CMD_SINE;
+    // double-buffered event counters: this launch appends to ev_count[] and clears the OTHER set for the next
     // launch, so the per-step host-side memset disappears from the stream
-    if (ev_count_next && blockIdx.x == 0 && threadIdx.x == 0) *ev_count_next = 0;
+    if (ev_count_next && blockIdx.x == 0 && threadIdx.x < FD_EV_SHARDS) ev_count_next[threadIdx.x] = 0;
 
     float o[FD_OBS_DIM];
 #pragma unroll
@@ -528,12 +548,12 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
     int32_t step = 0, episode = 0;
 
     if (active) {
-        const double* blk = s_params + lane_type(type, i, n_types) * FD_NP;
+        const double* blk = s_params + lane_type(type, i, n_types) * FD_NP_STAGED;
         Params<T> P; P.load(blk);
         Limits<S> Lm; Lm.load(blk);
 #pragma unroll
         for (int k = 0; k < FD_NX; ++k) x[k] = xs[k * n + i];
-        env_load<S>(e, es, n, i);
+        env_load<S>(e, es, n, i, uses_sched);
         step = eis[FD_EI_STEP * n + i];
         episode = eis[FD_EI_EPISODE * n + i];
 
@@ -640,24 +660,23 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
     }
 
     // ---- K4: episode-done compaction -- wave ballot + mbcnt prefix, one atomic per wave ---------------------
+    // The returning atomic is ISSUED here and its result consumed only after the auto-reset below: the reset work of the
+    // finished lanes (Philox draws / pool reads, first observation) covers the atomic's round trip.
     const unsigned long long done_mask = __ballot(done);
-    if (done_mask != 0ull && ev_count != nullptr) {
+    const bool compact = done_mask != 0ull && ev_count != nullptr;
+    int base = 0, prefix = 0;
+    const int shard = int(blockIdx.x) & (FD_EV_SHARDS - 1), cap_s = ev_cap / FD_EV_SHARDS;
+    if (compact) {
         const int n_done = __popcll(done_mask);
-        const int prefix = __builtin_amdgcn_mbcnt_hi(uint32_t(done_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(done_mask), 0u));
+        prefix = __builtin_amdgcn_mbcnt_hi(uint32_t(done_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(done_mask), 0u));
         const int leader = __ffsll((long long)done_mask) - 1;
-        int base = 0;
-        if (lane == leader) base = atomicAdd(ev_count, n_done);
-        base = __shfl(base, leader, FD_WAVE);
-        const int slot = base + prefix;
-        if (done && slot < ev_cap) {
-            ev_int[slot * FD_EV_NI + FD_EV_ENV] = int32_t(i);
-            ev_int[slot * FD_EV_NI + FD_EV_LENGTH] = step;
-            ev_int[slot * FD_EV_NI + FD_EV_TERMINATED] = term ? 1 : 0;
-            ev_flt[slot * FD_EV_NF] = float(e.ep_return);
-#pragma unroll
-            for (int k = 0; k < FD_OBS_DIM; ++k) ev_flt[slot * FD_EV_NF + 1 + k] = o[k];
-        }
+        if (lane == leader) base = atomicAdd(ev_count + shard, n_done);
     }
+    float o_term[FD_OBS_DIM];                                                     // terminal observation of a finished episode
+#pragma unroll
+    for (int k = 0; k < FD_OBS_DIM; ++k) o_term[k] = o[k];
+    const float ret_term = done ? float(e.ep_return) : 0.0f;
+    const int32_t len_term = step;
 
     // ---- in-kernel auto-reset (vec-env semantics: the returned observation is the post-reset one) -----------
     if (active) {
@@ -674,11 +693,25 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
         }
 #pragma unroll
         for (int k = 0; k < FD_NX; ++k) xs[k * n + i] = x[k];
-        env_store<S>(e, es, n, i);
+        env_store<S>(e, es, n, i, uses_sched);
         eis[FD_EI_STEP * n + i] = step;
         eis[FD_EI_EPISODE * n + i] = episode;
     }
-    store_obs_tile(s_tile[wave], o, lane, obs_out, lm.wave_first, n, lpw);
+    if (compact) {
+        const int leader = __ffsll((long long)done_mask) - 1;
+        base = __shfl(base, leader, FD_WAVE);
+        const int local = base + prefix;
+        if (done && local < cap_s) {
+            const int slot = shard * cap_s + local;
+            ev_int[slot * FD_EV_NI + FD_EV_ENV] = int32_t(i);
+            ev_int[slot * FD_EV_NI + FD_EV_LENGTH] = len_term;
+            ev_int[slot * FD_EV_NI + FD_EV_TERMINATED] = term ? 1 : 0;
+            ev_flt[slot * FD_EV_NF] = ret_term;
+#pragma unroll
+            for (int k = 0; k < FD_OBS_DIM; ++k) ev_flt[slot * FD_EV_NF + 1 + k] = o_term[k];
+        }
+    }
+    store_obs_tile(s_tile[wave], o, lane, obs_out, lm.wave_first, n);
 }
 
 // =========================================================================================================
@@ -686,28 +719,14 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
 // =========================================================================================================
 static inline unsigned grid_for(int64_t n) { return unsigned((n + FD_BLOCK - 1) / FD_BLOCK); }
 
-// lanes-per-wave policy (see lane_map): enough waves for >= 2 per SIMD on the whole chip, never below 16 lanes.
-static int g_lpw_override = 0, g_simds = 0;
-static int pick_lpw(int64_t n)
+static int g_simds = 0;
+static int simd_count()
 {
-    if (g_lpw_override) return g_lpw_override;
     if (!g_simds) {
         int dev = 0; hipDeviceProp_t p;
         g_simds = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount * 4 : 1024;
-        const char* e = getenv("FDYN_LPW");
-        if (e) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) g_lpw_override = v; }
-        if (g_lpw_override) return g_lpw_override;
     }
-    // Measured on MI355X at N = 65 536 (mixed env step): lpw 64 -> 67.8 us, 32 -> 99.9 us, 16 -> 182.7 us.  The SIMD
-    // already retires ~1 VALU per 5 cycles from a single wave and only reaches ~1 per 3.4 with four, so doubling the
-    // instruction count to double the wave count loses.  Fully populated waves stay the default.
-    (void)n;
-    return 64;
-}
-static inline unsigned grid_lpw(int64_t n, int lpw)
-{
-    const int64_t waves = (n + lpw - 1) / lpw;
-    return unsigned((waves + (FD_BLOCK / FD_WAVE) - 1) / (FD_BLOCK / FD_WAVE));
+    return g_simds;
 }
 static inline int launch_status() { return int(hipGetLastError()); }
 
@@ -727,11 +746,10 @@ int fdyn_num_substeps(double dt, double dt_physics)
     return n < 1 ? 1 : int(n);
 }
 
-int fdyn_set_lanes_per_wave(int lpw)
-{   // 0 = automatic (default); 16 / 32 / 64 force the lane population of every fleet kernel (tuning / experiments)
-    if (lpw != 0 && lpw != 16 && lpw != 32 && lpw != 64) return FDYN_ERR_BAD_SIZE;
-    g_lpw_override = lpw;
-    return FDYN_OK;
+int64_t fdyn_event_capacity(int64_t n)
+{   // every shard must hold all the envs of the workgroups that map to it
+    const int64_t blocks = (n + FD_BLOCK - 1) / FD_BLOCK;
+    return FD_EV_SHARDS * ((blocks + FD_EV_SHARDS - 1) / FD_EV_SHARDS) * FD_BLOCK;
 }
 
 int fdyn_device_info(int* cu_count, int* wave_size, char* arch, int arch_len)
@@ -757,9 +775,8 @@ int fdyn_device_info(int* cu_count, int* wave_size, char* arch, int arch_len)
         const double dt_sub = dt / n_sub;                                                                    \
         /* simplified_6dof.py:241-245: dt <= min_timestep or > max_timestep raises ValueError (defaults) */ \
         if (!(dt_sub > 1e-6) || dt_sub > 1.0) return FDYN_ERR_BAD_DT;                                        \
-        const int lpw = pick_lpw(n);                                                                         \
-        hipLaunchKernelGGL((sixdof_step_kernel<S, T>), dim3(grid_lpw(n, lpw)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
-                           x, u, type, params, n_types, n, S(dt_sub), n_sub, derived_out, lpw);              \
+        hipLaunchKernelGGL((sixdof_step_kernel<S, T>), dim3(grid_for(n)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
+                           x, u, type, params, n_types, n, S(dt_sub), n_sub, derived_out);              \
         return launch_status();                                                                              \
     }
 FD_DEFINE_SIXDOF(fdyn_sixdof_step_f64, double, double)
@@ -796,10 +813,9 @@ int fdyn_pid_compute_batch(const float* cfg, int cfg_per_lane, float* state, con
         FD_CHECK_COMMON(n, n_types)                                                                          \
         if (n_wp < 1 || n_wp > FD_MAX_WAYPOINTS || n_steps < 0) return FDYN_ERR_BAD_SIZE;                    \
         if (!(dt > 1e-6) || dt > 1.0) return FDYN_ERR_BAD_DT;                                                \
-        const int lpw = pick_lpw(n);                                                                         \
-        hipLaunchKernelGGL((cascade_step_kernel<S, T>), dim3(grid_lpw(n, lpw)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
+        hipLaunchKernelGGL((cascade_step_kernel<S, T>), dim3(grid_for(n)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
                            x, pid_state, wp_idx, type, params, n_types, pid_cfg, consts, wps, n_wp, n, S(dt), \
-                           n_steps, surf_out, reached_total, lpw);                                           \
+                           n_steps, surf_out, reached_total);                                           \
         return launch_status();                                                                              \
     }
 #define FD_DEFINE_AGENT(NAME, S, T)                                                                          \
@@ -811,10 +827,9 @@ int fdyn_pid_compute_batch(const float* cfg, int cfg_per_lane, float* state, con
         if (level < FD_LEVEL_WAYPOINT || level > FD_LEVEL_RATE || n_steps < 0) return FDYN_ERR_BAD_SIZE;     \
         if (n > 0 && (!x || !pid_state || !pid_cfg || !consts || !cmd)) return FDYN_ERR_NULL;                \
         if (!(dt > 1e-6) || dt > 1.0) return FDYN_ERR_BAD_DT;                                                \
-        const int lpw = pick_lpw(n);                                                                         \
-        hipLaunchKernelGGL((agent_step_kernel<S, T>), dim3(grid_lpw(n, lpw)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
+        hipLaunchKernelGGL((agent_step_kernel<S, T>), dim3(grid_for(n)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
                            level, x, pid_state, type, params, n_types, pid_cfg, consts, cmd, n, S(dt), n_steps, \
-                           surf_out, lpw, cfg_per_lane);                                                     \
+                           surf_out, cfg_per_lane);                                                     \
         return launch_status();                                                                              \
     }
 FD_DEFINE_AGENT(fdyn_agent_step_f64, double, double)
@@ -832,9 +847,8 @@ FD_DEFINE_CASCADE(fdyn_cascade_step_f32, float, float)
     {                                                                                                        \
         FD_CHECK_COMMON(n, 1)                                                                                \
         if (pool && pool_depth < 1) return FDYN_ERR_BAD_SIZE;                                                \
-        const int lpw_r = pick_lpw(n);                                                                       \
-        hipLaunchKernelGGL((rate_env_reset_kernel<S>), dim3(grid_lpw(n, lpw_r)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
-                           x, e, ei, pid_state, mask, env_consts, pool, pool_depth, seed, obs_out, n, lpw_r); \
+        hipLaunchKernelGGL((rate_env_reset_kernel<S>), dim3(grid_for(n)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
+                           x, e, ei, pid_state, mask, env_consts, pool, pool_depth, seed, obs_out, n); \
         return launch_status();                                                                              \
     }                                                                                                        \
     int fdyn_rate_env_step_##SUFFIX(S* x, S* e, int32_t* ei, const uint8_t* type, const double* params,      \
@@ -852,21 +866,20 @@ FD_DEFINE_CASCADE(fdyn_cascade_step_f32, float, float)
         if ((!actions || residual_scale > 0.0f) && !(pid_state && pid_cfg && casc_consts)) return FDYN_ERR_NULL; \
         if (!obs_out || !terminated || !truncated || !env_consts) return FDYN_ERR_NULL;                      \
         if (ev_count && (!ev_int || !ev_flt || ev_cap < 0)) return FDYN_ERR_NULL;                            \
-        const int lpw = pick_lpw(n);                                                                         \
-        if (sizeof(T) == 4 && g_simds > 0 && n > int64_t(g_simds) * FD_WAVE)   /* pick_lpw has filled g_simds */   \
-            hipLaunchKernelGGL((rate_env_step_kernel<S, T, true>), dim3(grid_lpw(n, lpw)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
+        if (sizeof(T) == 4 && n > int64_t(simd_count()) * FD_WAVE)   /* more than one wave per SIMD */            \
+            hipLaunchKernelGGL((rate_env_step_kernel<S, T, true>), dim3(grid_for(n)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
                            x, e, ei, type, params, n_types, env_consts, actions, pid_state, pid_cfg,         \
                            casc_consts, actions_out, rw_delta, pool, pool_depth, seed, auto_reset,           \
                            residual_scale, obs_out,                                                          \
                            reward_f32, reward_full, terminated, truncated, ev_count, ev_count_next, ev_int, ev_flt,  \
-                           ev_cap, n, lpw);                                                                  \
+                           ev_cap, n);                                                                  \
         else                                                                                                 \
-            hipLaunchKernelGGL((rate_env_step_kernel<S, T, false>), dim3(grid_lpw(n, lpw)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
+            hipLaunchKernelGGL((rate_env_step_kernel<S, T, false>), dim3(grid_for(n)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
                            x, e, ei, type, params, n_types, env_consts, actions, pid_state, pid_cfg,         \
                            casc_consts, actions_out, rw_delta, pool, pool_depth, seed, auto_reset,           \
                            residual_scale, obs_out,                                                          \
                            reward_f32, reward_full, terminated, truncated, ev_count, ev_count_next, ev_int, ev_flt,  \
-                           ev_cap, n, lpw);                                                                  \
+                           ev_cap, n);                                                                  \
         return launch_status();                                                                              \
     }
 FD_DEFINE_ENV(f64, double, double)

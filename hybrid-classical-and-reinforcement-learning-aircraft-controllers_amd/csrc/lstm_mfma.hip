@@ -16,8 +16,8 @@
 //   * B operand (weights): streamed through LDS in chunks of 64 weight rows (a gate PAIR x 32 hidden units) x KC
 //     columns, rows padded by 16 B so a ds_read_b128 of 16 consecutive rows touches all 64 banks once (measured:
 //     SQ_LDS_BANK_CONFLICT = 0).  Every wave reads the same chunk: one global read per workgroup, 4x LDS reuse.  Chunks
-//     ping-pong between two LDS buffers; the next chunk is prefetched into registers under the current chunk's MFMAs.
-//     Two workgroups are resident per CU (50 KB LDS, <= 256 VGPRs each).
+//     rotate through three LDS buffers filled by LDS-DMA two chunks ahead of the MFMAs.
+//     Two workgroups are resident per CU (75 KB LDS, <= 256 VGPRs each).
 //   * per hidden slice (32 units) a wave makes two passes over K: gates (i, g) -> sigmoid(i) tanh(g), then (f, o).
 //     Lane (c, hf) owns hidden unit c of the slice for 16 batch rows in every 32x32 accumulator, so the cell update is
 //     purely lane-local; h' (bf16) and c' (fp32) go straight from registers to HBM.
@@ -72,182 +72,13 @@ __device__ __forceinline__ uint16_t f2bf(float f)
 //
 // Register budget is what shapes this kernel (256 VGPRs at two waves per SIMD): the activation slab is 96, so the four
 // gates of a slice are produced as two PAIRS -- (i, g) first, folded to sigmoid(i)*tanh(g) (16 registers), then (f, o) --
-// which halves the live accumulators (32) and leaves room to prefetch the next weight chunk into registers while the
-// current chunk's MFMAs run.  Weight chunks (64 rows x KC) ping-pong between two LDS buffers: one barrier per chunk.
-template <int KX, int KH>
-__global__ void __launch_bounds__(256, 2)
-lstm_cell_mfma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const uint16_t* __restrict__ h_prev /*[B][KH] bf16*/,
-                      const float* __restrict__ c_prev /*[B][H]*/, const float* __restrict__ keep /*[B] or null*/,
-                      const uint16_t* __restrict__ W /*[4H][KX+KH] bf16*/, const float* __restrict__ bias /*[4H]*/,
-                      uint16_t* __restrict__ h_out /*[B][H] bf16*/, float* __restrict__ c_out /*[B][H]*/,
-                      float* __restrict__ h_out_f32 /*[B][H] or null*/, int64_t B, int H, int split)
-{
-    constexpr int K = KX + KH;
-    constexpr int KSTEPS = K / 16;
-    constexpr int NCHUNK = (K + 191) / 192;               // K-chunks per pass: 384 -> 2 x 192, 256 -> 2 x 128, 128 -> 1
-    constexpr int KC = K / NCHUNK;
-    constexpr int KC_STEPS = KC / 16;
-    constexpr int ROW = KC + LDS_PAD;                     // padded LDS row (bf16 elements)
-    constexpr bool RECUR = KH > 0;
-    constexpr int THREADS = 256;
-    constexpr int CROWS = 2 * NSLICE;                     // weight rows per chunk: one gate pair x 32 hidden units
-    constexpr int VEC_PER_ROW = KC / 8;
-    constexpr int TOTAL_VEC = CROWS * VEC_PER_ROW;
-    constexpr int NV = TOTAL_VEC / THREADS;               // 16-B vectors each thread moves per chunk (4 or 6)
-    static_assert(TOTAL_VEC % THREADS == 0 && NV <= 6, "chunk must divide evenly over the workgroup");
-    constexpr int BUF = CROWS * ROW;
-    __shared__ __attribute__((aligned(16))) uint16_t s_w[2 * BUF];
-    __shared__ float s_keep[BM];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, hf = lane >> 5;
-    const int64_t row0 = int64_t(blockIdx.x) * BM + wave * 32;
-    const int64_t my_row = row0 + r;                      // A-operand row of this lane
-    const bool row_ok = my_row < B;
-    // `split` workgroups share one 128-row block, each taking n_slices / split of the hidden slices (blockIdx.y): small
-    // batches (B / 128 < 2 x CUs) would otherwise leave most of the chip idle.  Costs one extra read of the row block's
-    // activation slab per split.
-    const int n_slices = (H / NSLICE) / split;
-    const int slice0 = int(blockIdx.y) * n_slices;
-
-    // chunk (sl, pass, ch): 64 weight rows = gates (pass, pass + 2) of hidden units sl*32 .. +31, columns ch*KC .. +KC;
-    // pass 0 = (i, g), pass 1 = (f, o).  Zero-state layers have no use for f: their pass 1 still stages (f, o) -- every
-    // address stays inside W -- but only multiplies the o half.
-    // Source offset = [uniform: chunk origin] + [per-thread constant: row/vector inside the chunk], so each load is
-    // "scalar base + one 32-bit VGPR offset" and the address math costs 6 registers for the whole kernel.
-    // Staging registers and offsets are named scalars: arrays here end up in scratch memory.
-#define FD_LOFF(I) (((((tid + I * THREADS) / VEC_PER_ROW) >> 5) * 2 * H + (((tid + I * THREADS) / VEC_PER_ROW) & 31)) * K + ((tid + I * THREADS) % VEC_PER_ROW) * 8)
-#define FD_LDST(I) (((tid + I * THREADS) / VEC_PER_ROW) * ROW + ((tid + I * THREADS) % VEC_PER_ROW) * 8)
-    const int loff0 = FD_LOFF(0), loff1 = FD_LOFF(1), loff2 = FD_LOFF(2), loff3 = FD_LOFF(3), loff4 = FD_LOFF(4), loff5 = FD_LOFF(5);
-    const int ldst0 = FD_LDST(0), ldst1 = FD_LDST(1), ldst2 = FD_LDST(2), ldst3 = FD_LDST(3), ldst4 = FD_LDST(4), ldst5 = FD_LDST(5);
-    (void)loff4; (void)loff5; (void)ldst4; (void)ldst5;
-#define FD_ORIGIN(SL, PASS, CH) (W + (int64_t(PASS) * H + (SL) * NSLICE) * K + (CH) * KC)
-#define FD_F1(I, ORG) if constexpr (NV > I) stage##I = *reinterpret_cast<const uint4*>((ORG) + loff##I);
-#define FD_C1(I, BUFI) if constexpr (NV > I) *reinterpret_cast<uint4*>(s_w + (BUFI) * BUF + ldst##I) = stage##I;
-#define FD_FETCH(SL, PASS, CH) { const uint16_t* org_ = FD_ORIGIN(SL, PASS, CH); FD_F1(0, org_) FD_F1(1, org_) FD_F1(2, org_) FD_F1(3, org_) FD_F1(4, org_) FD_F1(5, org_) }
-#define FD_COMMIT(BUFI) FD_C1(0, BUFI) FD_C1(1, BUFI) FD_C1(2, BUFI) FD_C1(3, BUFI) FD_C1(4, BUFI) FD_C1(5, BUFI)
-
-    uint4 stage0, stage1, stage2, stage3, stage4, stage5;
-    stage0 = stage1 = stage2 = stage3 = stage4 = stage5 = make_uint4(0, 0, 0, 0);
-    // Workgroups walk the hidden slices in ROTATED order.  In natural order all 512 workgroups stream the same 25 KB of W
-    // at the same moment: in each XCD's L2 one hot line is served to 64 workgroups while the other channels idle (measured:
-    // the weight stream alone took 82 us = 0.6 TB/s per XCD).  Blocks b and b + 8 share an XCD (round-robin dispatch), so
-    // the rotation mixes b and b / 8: the workgroups of one XCD then have 8 different slices in flight.  Speed only -- any
-    // placement gives the same result.
-    const int sl_start = int((blockIdx.x + (blockIdx.x >> 3)) % unsigned(n_slices));   // b%8 and b/8 both rotate (measured best)
-#define FD_SL(I) (slice0 + ((I) + sl_start) % n_slices)
-    FD_FETCH(FD_SL(0), 0, 0)                              // start the weight stream before the activation slab
-
-    // ---- A slab -> registers (masked h part).  Branch-free: rows past B read row B-1 (their results are never stored) and
-    // the episode-start mask is a select, so all K/16 loads are in flight together (a guarded load per k-step makes
-    // hipcc branch and drain vmcnt around each one).
-    bf16x8_t a[KSTEPS];
-    {
-        const int64_t lrow = row_ok ? my_row : (B - 1);
-        const float kp = (RECUR && keep) ? keep[lrow] : 1.0f;
-        const uint16_t* xr = x + lrow * KX;
-        const uint16_t* hr = RECUR ? h_prev + lrow * KH : x;
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            const int k = 16 * s + 8 * hf;
-            uint4 v;
-            if (16 * s < KX) {
-                v = *reinterpret_cast<const uint4*>(xr + k);
-            } else {
-                v = *reinterpret_cast<const uint4*>(hr + (k - KX));
-                v = (kp != 0.0f) ? v : make_uint4(0, 0, 0, 0);
-            }
-            a[s] = __builtin_bit_cast(bf16x8_t, v);
-        }
-    }
-    if (RECUR) {
-        for (int i = tid; i < BM; i += THREADS) {
-            const int64_t b = int64_t(blockIdx.x) * BM + i;
-            s_keep[i] = (keep && b < B) ? keep[b] : 1.0f;
-        }
-    }
-    FD_COMMIT(0)
-    __syncthreads();
-
-    int step = 0;                                         // chunk counter: buffer = step & 1
-    for (int si = 0; si < n_slices; ++si) {
-        const int sl = FD_SL(si);
-        const int col = sl * NSLICE + r;
-        float ig[16];
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            f32x16_t acc0, acc1;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { acc0[e] = 0.0f; acc1[e] = 0.0f; }
-#pragma unroll
-            for (int ch = 0; ch < NCHUNK; ++ch, ++step) {
-                const int buf = step & 1;
-                const bool last_ch = ch == NCHUNK - 1;
-                const bool has_next = !(si == n_slices - 1 && pass == 1 && last_ch);
-                if (has_next) {                               // next chunk: in flight during this chunk's MFMAs
-                    if (!last_ch) { FD_FETCH(sl, pass, ch + 1) }
-                    else if (pass == 0) { FD_FETCH(sl, 1, 0) }
-                    else { FD_FETCH(FD_SL(si + 1), 0, 0) }
-                }
-                const uint16_t* wb = s_w + buf * BUF;
-#pragma unroll
-                for (int ks = 0; ks < KC_STEPS; ++ks) {
-                    const bf16x8_t af = a[ch * KC_STEPS + ks];
-                    if (RECUR || pass == 0) {                 // rows 0..31 of the chunk: gate i (pass 0) / f (pass 1)
-                        const uint4 b0 = *reinterpret_cast<const uint4*>(wb + r * ROW + ks * 16 + hf * 8);
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8_t, b0), acc0, 0, 0, 0);
-                    }
-                    const uint4 b1 = *reinterpret_cast<const uint4*>(wb + (NSLICE + r) * ROW + ks * 16 + hf * 8);   // g / o
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8_t, b1), acc1, 0, 0, 0);
-                }
-                if (has_next) { FD_COMMIT(buf ^ 1) }
-                __syncthreads();                              // next buffer visible; this buffer free for step + 2
-            }
-            // C/D map of a 32x32 tile: col = lane & 31 (hidden unit), row = (e & 3) + 8 (e >> 2) + 4 hf
-            if (pass == 0) {
-                const float bi = bias[col], bg = bias[2 * H + col];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) ig[e] = sigmoid_(acc0[e] + bi) * tanh_(acc1[e] + bg);
-            } else {
-                const float bo = bias[3 * H + col], bf = RECUR ? bias[H + col] : 0.0f;
-                // Addresses: [per-wave base pointer] + [one 32-bit per-lane offset] + [compile-time row constant * H].
-                // Written as b * H + col per element, LLVM hoists sixteen 64-bit row addresses per output array out of
-                // the slice loop and the activation slab spills.
-                const bool full = row0 + 32 <= B;             // wave-uniform: every row of this wave's tile exists
-                const int lane_off = hf * 4 * H + col;
-                const int64_t wave_off = (row0 < B ? row0 : 0) * H;      // a wave wholly past B reads row 0, stores nothing
-                const int rows_left = row0 < B ? int(B - row0 < 32 ? B - row0 : 32) : 0;   // rows of this tile that exist
-                float cp[16];                                 // all 16 c_prev loads issued together (clamped row)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int lr = (e & 3) + 8 * (e >> 2) + 4 * hf;
-                    const int off = (full || lr < rows_left) ? lane_off + ((e & 3) + 8 * (e >> 2)) * H : col;
-                    cp[e] = RECUR ? c_prev[wave_off + off] : 0.0f;
-                }
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int lr = (e & 3) + 8 * (e >> 2) + 4 * hf;
-                    const int off = lane_off + ((e & 3) + 8 * (e >> 2)) * H;
-                    float c = ig[e];
-                    float go;
-                    if (RECUR) c += sigmoid_(acc0[e] + bf) * (s_keep[wave * 32 + lr] * cp[e]);
-                    go = sigmoid_(acc1[e] + bo);
-                    const float hv = go * tanh_(c);
-                    if (full || lr < rows_left) {
-                        if (c_out) c_out[wave_off + off] = c;
-                        h_out[wave_off + off] = f2bf(hv);
-                        if (h_out_f32) h_out_f32[wave_off + off] = hv;
-                    }
-                }
-            }
-        }
-    }
-}
-
-// The same cell with the weight stream moved by LDS-DMA (global_load_lds_dwordx4, new on gfx950): a chunk goes from L2
-// straight into LDS without passing through registers, so three LDS buffers can be kept in rotation and chunk q + 2 is
-// requested while chunk q is multiplied -- twice the prefetch distance of the register-staged version, whose chunk period
-// was set by the L2 round trip (rocprofv3: MFMA pipe 25 % busy, a third of the wave cycles waiting on VMEM).
+// which halves the live accumulators (32).
+//
+// The weight stream moves by LDS-DMA (global_load_lds_dwordx4, new on gfx950): a chunk goes from L2 straight into LDS
+// without passing through registers, so three LDS buffers are kept in rotation and chunk q + 2 is requested while chunk q
+// is multiplied.  (A register-staged double-buffered version of this kernel was measured at 98.7 us against 93.5 us and
+// removed in round 2: its chunk period was set by the L2 round trip -- MFMA pipe 25 % busy, a third of the wave cycles
+// waiting on VMEM.)
 // DMA layout rule: the 64 lanes of one instruction write 64 consecutive 16-byte slots of LDS; the padded chunk (64 rows x
 // (KC + 8) bf16) is therefore moved as 64 * (KC/8 + 1) slots, the pad slot of each row re-reading the row's last vector.
 // Wave w issues slot groups w, w + 4, ...; each wave waits for its own groups (vmcnt) before the chunk barrier.
@@ -465,15 +296,9 @@ int launch(const void* x, const void* h_prev, const float* c_prev, const float* 
     int split = 1;                                        // aim for >= 2 workgroups per CU, split a power of two <= H/32
     while (split < H / NSLICE && row_blocks * split < int64_t(2) * cus) split *= 2;
     while ((H / NSLICE) % split) split /= 2;
-    static int use_dma = -1;                              // FDYN_MFMA_DMA=0 selects the register-staged weight stream
-    if (use_dma < 0) { const char* e = getenv("FDYN_MFMA_DMA"); use_dma = (e && e[0] == '0') ? 0 : 1; }
-    if (use_dma)
-        hipLaunchKernelGGL((lstm_cell_mfma_dma_kernel<KX, KH>), dim3(unsigned(row_blocks), unsigned(split)), dim3(256), 0, st,
-                           (const uint16_t*)x, (const uint16_t*)h_prev, c_prev, keep, (const uint16_t*)W, bias, (uint16_t*)h_out, c_out,
-                           h_out_f32, B, H, split);
-    else
-        hipLaunchKernelGGL((lstm_cell_mfma_kernel<KX, KH>), dim3(unsigned(row_blocks), unsigned(split)), dim3(256), 0, st, (const uint16_t*)x,
-                           (const uint16_t*)h_prev, c_prev, keep, (const uint16_t*)W, bias, (uint16_t*)h_out, c_out, h_out_f32, B, H, split);
+    hipLaunchKernelGGL((lstm_cell_mfma_dma_kernel<KX, KH>), dim3(unsigned(row_blocks), unsigned(split)), dim3(256), 0, st,
+                       (const uint16_t*)x, (const uint16_t*)h_prev, c_prev, keep, (const uint16_t*)W, bias, (uint16_t*)h_out, c_out,
+                       h_out_f32, B, H, split);
     return int(hipGetLastError());
 }
 

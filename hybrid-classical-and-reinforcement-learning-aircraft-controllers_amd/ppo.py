@@ -61,6 +61,7 @@ class FlatGrad:
         self.params = [p for p in module.parameters() if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         self.buf = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
+        self.events = None           # a list => every collective is bracketed by HIP events on the stream that waits for it
         off = 0
         for p in self.params:
             p.grad = self.buf[off:off + p.numel()].view_as(p)
@@ -71,7 +72,14 @@ class FlatGrad:
 
     def all_reduce_mean(self):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            timed = self.events is not None and self.buf.is_cuda
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)
+            if timed:
+                e1.record()
+                self.events.append((e0, e1))
             self.buf.div_(dist.get_world_size())
 
     def clip_norm_(self, max_norm: float):
@@ -145,10 +153,16 @@ class RecurrentPPO:
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
         torch.manual_seed(seed + 7919 * (rank + 1))      # different exploration noise per rank
         N, T = env.num_envs, self.cfg.n_steps
+        if N % max(1, self.cfg.n_minibatches) != 0:
+            # env slices are fixed-size (one captured update graph serves every slice): a remainder would silently drop
+            # envs from every epoch
+            raise ValueError(f"num_envs ({N}) must be a multiple of n_minibatches ({self.cfg.n_minibatches})")
         f32 = dict(dtype=torch.float32, device=self.device)
         self.buf_obs = torch.zeros((T, N, 18), **f32)
         self.buf_act = torch.zeros((T, N, 4), **f32)
         self.buf_rew, self.buf_val, self.buf_logp, self.buf_start = (torch.zeros((T, N), **f32) for _ in range(4))
+        # time-limit bootstrap term gamma * V(.), kept OUT of buf_rew: GAE sees rew + boot, the logs see the env's own rewards
+        self.buf_boot = torch.zeros((T, N), **f32) if self.cfg.bootstrap_timeouts else None
         self.obs = env.reset()                           # aliases the env's observation buffer (rewritten every step)
         self._alloc_states(N)
         self.episode_start = torch.ones(N, **f32)
@@ -205,17 +219,19 @@ class RecurrentPPO:
                 # earlier), as large-batch GPU trainers do; SB3 (which the reference uses) evaluates the terminal observation
                 # itself -- that is bootstrap_timeouts=True below, at the price of a host sync per step.
                 timeout = (trunc & ~term).float() if trunc.dtype == torch.bool else ((trunc != 0) & (term == 0)).float()
-                self.buf_rew[t].addcmul_(values, timeout, value=cfg.gamma)
+                torch.mul(values, timeout, out=self.buf_boot[t])
+                self.buf_boot[t].mul_(cfg.gamma)
             elif cfg.bootstrap_timeouts:
                 # time-limit truncation is not failure: add gamma * V(s_T) (vec-env 'TimeLimit.truncated' handling).
                 # The post-step critic state belongs to the finished episode, so it can value the terminal observation.
                 ints, flts = env.episode_events()                     # host sync: this option disables graph replay
+                self.buf_boot[t].zero_()
                 if ints.shape[0]:
                     tr = ints[:, 2] == 0
                     if bool(tr.any()):
                         ids = ints[tr, 0].long()
                         v = pol.predict_values(flts[tr, 1:], new_states.index(ids), torch.zeros(ids.numel(), device=self.device))
-                        self.buf_rew[t, ids] += cfg.gamma * v
+                        self.buf_boot[t, ids] = cfg.gamma * v
             if obs.data_ptr() != self.obs.data_ptr():
                 self.obs.copy_(obs)                               # (self.obs aliases the env's observation buffer on the GPU)
             for dst, src in zip(nxt, new_states):
@@ -245,7 +261,8 @@ class RecurrentPPO:
             self._rollout_body()
         self.num_timesteps += cfg.n_steps * self.env.num_envs
         last_values = pol.predict_values(self.obs, self.states, self.episode_start)
-        self.adv, self.ret = compute_gae(self.buf_rew, self.buf_val, self.buf_start, last_values, self.episode_start,
+        rew = self.buf_rew if self.buf_boot is None else self.buf_rew + self.buf_boot
+        self.adv, self.ret = compute_gae(rew, self.buf_val, self.buf_start, last_values, self.episode_start,
                                          cfg.gamma, cfg.gae_lambda)
 
     def _minibatch_loss(self, obs, act, starts, adv, ret, old_logp, old_v, states):

@@ -51,11 +51,12 @@ class GpuRateVecEnv:
         self.terminated = torch.zeros(n, dtype=torch.uint8, device=dev)
         self.truncated = torch.zeros(n, dtype=torch.uint8, device=dev)
         self.actions_taken = torch.zeros((n, L.FD_ACT_DIM), dtype=torch.float32, device=dev)
-        # compacted episode-end records
-        self.ev_cap = int(event_capacity if event_capacity is not None else n)
-        self._ev_counts = torch.zeros(2, dtype=torch.int32, device=dev)      # ping-pong counters (kernel clears the other)
+        # compacted episode-end records: FD_EV_SHARDS segments, one counter each (one fleet-wide atomic word saturates)
+        self.ev_cap = int(event_capacity if event_capacity is not None else self.lib.fdyn_event_capacity(n))
+        self._ev_cap_shard = self.ev_cap // L.FD_EV_SHARDS
+        self._ev_counts = torch.zeros((2, L.FD_EV_SHARDS), dtype=torch.int32, device=dev)   # ping-pong sets (kernel clears the other)
         self._ev_slot = 0
-        self.ev_count = self._ev_counts[0:1]
+        self._ev_cur = self._ev_counts[0]
         self.ev_int = torch.zeros((max(self.ev_cap, 1), L.FD_EV_NI), dtype=torch.int32, device=dev)
         self.ev_flt = torch.zeros((max(self.ev_cap, 1), L.FD_EV_NF), dtype=torch.float32, device=dev)
         # fused PID demonstrator (learned_controllers/utils/pid_demonstrations.py:41-77)
@@ -108,12 +109,15 @@ class GpuRateVecEnv:
             assert actions.shape == (self.n, L.FD_ACT_DIM)
         if rw_delta is not None:                               # random-walk command increments [3][N] in the state dtype
             assert rw_delta.shape == (3, self.n) and rw_delta.dtype == self.dtype and rw_delta.device == self.x.device
-        cur, nxt = self._ev_counts[self._ev_slot:self._ev_slot + 1], self._ev_counts[1 - self._ev_slot:2 - self._ev_slot]
-        self.ev_count, self._ev_slot = cur, 1 - self._ev_slot
+        # `actions_taken` is written only where the action is made in-kernel (fused PID demonstrator, residual env): with a
+        # policy's own actions it would be a 16-B-per-env copy of the input
+        acts_out = self.actions_taken if (actions is None or self.residual_scale > 0.0) else None
+        cur, nxt = self._ev_counts[self._ev_slot], self._ev_counts[1 - self._ev_slot]
+        self._ev_cur, self._ev_slot = cur, 1 - self._ev_slot
         rc = self._step_fn(_lib.ptr(self.x), _lib.ptr(self.e), _lib.ptr(self.ei), _lib.ptr(self.type_index),
                            _lib.ptr(self.params), self.n_types, _lib.ptr(self.env_consts), _lib.ptr(actions),
                            _lib.ptr(self.pid_state), _lib.ptr(self.pid_cfg), _lib.ptr(self.casc_consts),
-                           _lib.ptr(self.actions_taken), _lib.ptr(rw_delta), _lib.ptr(self.pool), self.pool_depth,
+                           _lib.ptr(acts_out), _lib.ptr(rw_delta), _lib.ptr(self.pool), self.pool_depth,
                            self.seed_value, int(auto_reset), self.residual_scale, _lib.ptr(self.obs), _lib.ptr(self.rewards),
                            _lib.ptr(self.rewards_full), _lib.ptr(self.terminated), _lib.ptr(self.truncated),
                            cur.data_ptr(), nxt.data_ptr(), _lib.ptr(self.ev_int), _lib.ptr(self.ev_flt), self.ev_cap,
@@ -146,12 +150,14 @@ class GpuRateVecEnv:
             io = self._host_io()
             torch.bitwise_or(term, trunc, out=io["done_dev"])
             io["obs"].copy_(obs, non_blocking=True); io["rew"].copy_(rew, non_blocking=True)
-            io["done"].copy_(io["done_dev"], non_blocking=True); io["count"].copy_(self.ev_count, non_blocking=True)
+            io["done"].copy_(io["done_dev"], non_blocking=True); io["count"].copy_(self._ev_cur, non_blocking=True)
             torch.cuda.current_stream(self.device).synchronize()
-            k = min(int(io["count"][0]), self.ev_cap)
-            if k > 0:                                                # the records of the few episodes that just ended
-                io["ev_int"][:k].copy_(self.ev_int[:k], non_blocking=True)
-                io["ev_flt"][:k].copy_(self.ev_flt[:k], non_blocking=True)
+            k = 0
+            if int(io["count"].sum()) > 0:                           # the records of the few episodes that just ended
+                ints, flts = self._gather_events(io["count"].tolist())
+                k = ints.shape[0]
+                io["ev_int"][:k].copy_(ints, non_blocking=True)
+                io["ev_flt"][:k].copy_(flts, non_blocking=True)
                 torch.cuda.current_stream(self.device).synchronize()
             infos = self._infos_from(io["ev_int"][:k].numpy(), io["ev_flt"][:k].numpy())
             return io["obs"].numpy().copy(), io["rew"].numpy().copy(), io["done"].numpy().astype(bool), infos
@@ -165,7 +171,7 @@ class GpuRateVecEnv:
             self._io = {"act": act, "act_np": act.numpy(), "act_dev": torch.empty((self.n, L.FD_ACT_DIM), dtype=torch.float32, device=self.device),
                         "obs": pin(tuple(self.obs.shape), self.obs.dtype), "rew": pin(tuple(self.rewards.shape), self.rewards.dtype),
                         "done": pin((self.n,), torch.uint8), "done_dev": torch.empty(self.n, dtype=torch.uint8, device=self.device),
-                        "count": pin((1,), self.ev_count.dtype), "ev_int": pin(tuple(self.ev_int.shape), self.ev_int.dtype),
+                        "count": pin((L.FD_EV_SHARDS,), torch.int32), "ev_int": pin(tuple(self.ev_int.shape), self.ev_int.dtype),
                         "ev_flt": pin(tuple(self.ev_flt.shape), self.ev_flt.dtype)}
             self._info_list, self._info_dirty = [{} for _ in range(self.n)], []
         return self._io
@@ -196,10 +202,26 @@ class GpuRateVecEnv:
         a, self._pending = self._pending, None
         return self.step(a)
 
+    @property
+    def ev_count(self) -> torch.Tensor:
+        """[1] int32: episodes that ended in the last step (sum over the record shards)."""
+        return self._ev_cur.sum(dtype=torch.int32).reshape(1)
+
+    def _gather_events(self, counts):
+        """Dense (ints, floats) from the sharded record list; `counts` = the shard counters as a host list."""
+        cs = self._ev_cap_shard
+        segs = [(s * cs, min(int(c), cs)) for s, c in enumerate(counts) if c > 0]
+        if not segs:
+            return self.ev_int[:0], self.ev_flt[:0]
+        if len(segs) == 1:
+            lo, k = segs[0]
+            return self.ev_int[lo:lo + k], self.ev_flt[lo:lo + k]
+        idx = torch.cat([torch.arange(lo, lo + k, device=self.device) for lo, k in segs])
+        return self.ev_int.index_select(0, idx), self.ev_flt.index_select(0, idx)
+
     def episode_events(self):
-        """Compacted records of the episodes that ended in the last step (one small D2H copy of the count)."""
-        k = min(int(self.ev_count.item()), self.ev_cap)
-        return self.ev_int[:k], self.ev_flt[:k]
+        """Compacted records of the episodes that ended in the last step (one small D2H copy of the shard counters)."""
+        return self._gather_events(self._ev_cur.tolist())
 
     def episode_infos(self):
         """Per-env info dicts in the vec-env convention: `episode` = {r, l}, `terminal_observation`."""

@@ -64,8 +64,8 @@ extern "C" {
 int fdyn_abi_version(void);
 int fdyn_num_substeps(double dt, double dt_physics);
 int fdyn_device_info(int* cu_count /*host*/, int* wave_size /*host*/, char* arch /*host*/, int arch_len);
-/* lanes populated per wave64 in the fleet kernels: 0 = automatic (>= 2 waves per SIMD when N allows), or 16/32/64 */
-int fdyn_set_lanes_per_wave(int lpw);
+/* smallest ev_cap with which fdyn_rate_env_step_* can never drop an episode-end record of an n-env fleet */
+int64_t fdyn_event_capacity(int64_t n);
 
 /* ---- physics ------------------------------------------------------------------------------------------------
  * x      [FD_NX][n]  state, updated in place
@@ -132,10 +132,11 @@ int fdyn_agent_step_f32(int level, float* x, float* pid_state, const uint8_t* ty
  *        (learned_controllers/envs/residual_rate_env.py:99-157): action = clip(PID + scale * actions), reward += bonus
  *        auto_reset != 0: envs that end are reset in-kernel and obs_out holds the post-reset observation
  *        reward_f32 [n] / reward_full [n] (either may be NULL) ; terminated, truncated [n] uint8
- *        ev_count [1] int32 (must be 0 on entry), ev_int [ev_cap][FD_EV_NI], ev_flt [ev_cap][FD_EV_NF]: compacted
- *        episode-end records (env id, length, terminated | return, terminal observation); NULL = no records.
- *        ev_count_next [1] or NULL: a second counter this launch clears, so two counters can be ping-ponged
- *        across steps without a memset on the stream                                                         */
+ *        ev_count [FD_EV_SHARDS] int32 (must be 0 on entry), ev_int [ev_cap][FD_EV_NI], ev_flt [ev_cap][FD_EV_NF]:
+ *        compacted episode-end records (env id, length, terminated | return, terminal observation) in FD_EV_SHARDS
+ *        segments of ev_cap / FD_EV_SHARDS records (fdyn_layout.h); NULL = no records.
+ *        ev_count_next [FD_EV_SHARDS] or NULL: a second counter set this launch clears, so two sets can be
+ *        ping-ponged across steps without a memset on the stream                                              */
 #define FDYN_DECLARE_ENV(SUFFIX, S)                                                                             \
     int fdyn_rate_env_reset_##SUFFIX(S* x, S* e, int32_t* ei, float* pid_state, const uint8_t* mask,            \
                                      const double* env_consts, const double* pool, int pool_depth,              \

@@ -39,7 +39,12 @@ enum {
     FD_P_MAX_ACCELERATION, FD_P_MAX_ANGULAR_ACCELERATION,
     FD_P_MAX_TIMESTEP, FD_P_MIN_TIMESTEP,
     FD_NP_USED,
-    FD_NP = 48                         /* padded block stride (words) */
+    FD_NP = 48,                        /* padded block stride (words) of the caller's array */
+    /* derived words: exist only in the kernels' OWN staged (LDS) copy of a block, whose stride is FD_NP_STAGED; callers
+     * never see them */
+    FD_PD_INV_MASS = FD_NP_USED, FD_PD_INV_IXX, FD_PD_INV_IYY, FD_PD_INV_IZZ, FD_PD_SIN_MAX_ALPHA, FD_PD_COS_MAX_ALPHA,
+    FD_PD_INV_THRUST_ZERO_V, FD_PD_TAN_ALPHA_FAST, FD_PD_ALPHA_NEEDS_ATAN2, FD_PD_SIN_MAX_PITCH, FD_PD_COS_MAX_PITCH,
+    FD_NP_STAGED = 52
 };
 
 /* ---- scalar PID, cpp/include/pid_controller.h:22-49 and cpp/src/pid_controller.cpp:24-60 ----------- */
@@ -120,6 +125,12 @@ enum {
 enum { FD_EV_ENV = 0, FD_EV_LENGTH, FD_EV_TERMINATED, FD_EV_NI = 3 };           /* int32 part      */
 /* float part: [0] = episode return, [1..18] = terminal observation                                  */
 #define FD_EV_NF (1 + FD_OBS_DIM)
+/* The record list is kept in FD_EV_SHARDS segments, each with its own counter: workgroup b appends to shard b % FD_EV_SHARDS.
+ * One counter for the whole fleet is ONE memory-side atomic word -- it saturates near 88 returning atomics per microsecond
+ * on MI355X, and a step in which most waves hold a finished episode (random actions: ~1000 waves) spent 11 us of its 51 us
+ * queueing on it (rocprofv3 SQ_WAIT_ANY, round 2).  Shard s owns records [s * cap_s, s * cap_s + count[s]) with
+ * cap_s = ev_cap / FD_EV_SHARDS; size ev_cap with fdyn_event_capacity(n) to never lose a record.                  */
+enum { FD_EV_SHARDS = 64 };
 
 /* ---- per-episode evaluation metrics, learned_controllers/eval/metrics.py:8-40 (field order of RateControlMetrics) */
 enum {

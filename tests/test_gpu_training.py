@@ -55,10 +55,13 @@ def test_timeout_bootstrap_path(mode):
         r.policy._noise_seed = 7
         torch.manual_seed(5)
         r.collect_rollout()
-    diff = boot.buf_rew - plain.buf_rew
-    assert torch.equal(boot.buf_act, plain.buf_act) and float(diff.abs().max()) > 0.0
+    # the bootstrap term lives in its own buffer: logged rewards stay the env's own, GAE sees rew + boot
+    assert torch.equal(boot.buf_act, plain.buf_act) and torch.equal(boot.buf_rew, plain.buf_rew)
+    diff = boot.buf_boot
+    assert plain.buf_boot is None and float(diff.abs().max()) > 0.0
     timeouts = (boot.buf_start[1:] > 0)                               # an episode start at t+1 = an episode end at t
     assert float(diff[:-1][~timeouts].abs().max()) == 0.0             # only steps that ended an episode were touched
+    assert not torch.equal(boot.adv, plain.adv)
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
