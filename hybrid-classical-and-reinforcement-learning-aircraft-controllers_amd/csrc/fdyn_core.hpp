@@ -74,6 +74,17 @@ FD_DEV void rotate_small(float s, float c, float d, float& so, float& co)
     so = __builtin_fmaf(s, cd, c * sd);
     co = __builtin_fmaf(c, cd, -(s * sd));
 }
+// cos(x): Taylor to x^8 while |x| <= 0.8 rad (truncation < 3e-8; a bank command is limited to 25 deg), full reduction beyond
+FD_DEV float cos_bounded(float x)
+{
+    const float z = x * x;
+    float p = __builtin_fmaf(z, 2.4801587e-5f, -1.3888889e-3f);
+    p = __builtin_fmaf(z, p, 4.1666668e-2f);
+    p = __builtin_fmaf(z, p, -0.5f);
+    float c = __builtin_fmaf(z, p, 1.0f);
+    if (__builtin_expect(!(z <= 0.64f), 0)) { float sn; sincos(x, sn, c); }
+    return c;
+}
 // atan(t) for |t| <= 0.7 with NO range reduction: t + t z P(z), z = t^2, degree-5 weighted least-squares fit on Chebyshev
 // nodes (max abs error 4.7e-8 in fp32 evaluation; scripts in DESIGN.md §4).  0.7 = tan(35 deg) covers the angle-of-attack
 // clip of every shipped aircraft type (30 deg), so alpha never needs the three-range atan2 in flight.
@@ -197,10 +208,16 @@ template <typename T> FD_DEV T deg2rad(double d) { return T(d * (FD_PI / 180.0))
 // (a + pi) % (2 pi) - pi with Python floor-mod: [-pi, pi)     controllers/utils/pid_utils.py:65
 template <typename T> FD_DEV T wrap_angle(T a)
 {
-    const T b = T(2.0 * FD_PI);
-    T m = M<T>::fmod(a + T(FD_PI), b);
-    if (m < T(0)) m += b;
-    return m - T(FD_PI);
+    if constexpr (sizeof(T) == 4) {
+        // fp32 glue of the reduced-precision variants: range reduction by rint (differs from the floor-mod form only in
+        // which of -pi / +pi represents the half-turn itself); ocml's fmodf is ~40 instructions
+        return __builtin_fmaf(-6.2831853071795865f, __builtin_rintf(a * 0.15915494309189535f), a);
+    } else {
+        const T b = T(2.0 * FD_PI);
+        T m = M<T>::fmod(a + T(FD_PI), b);
+        if (m < T(0)) m += b;
+        return m - T(FD_PI);
+    }
 }
 
 // ----- aircraft parameter block, converted to the compute type and held in registers ---------------------
@@ -245,20 +262,23 @@ template <typename T> struct Params {
     // lane, instead of every lane of every launch running fp64 ocml sin/cos and divisions before it can start (~400 VALU
     // of a 1600-VALU one-step launch).  Callers of the C-ABI never see them: params stays [n_types][FD_NP].
     //   lanes 0..4 : reciprocals (fp64 division: inv_mass is used by the fp64 parity path too)
-    //   lanes 5..6 : sin / cos of the alpha limit and of the pitch limit (fp64 ocml: the f64 variant never reads them, but
-    //                the fp32 variants' clip cases should not depend on a second sincos implementation)
+    //   lanes 5..6 : sin / cos of the alpha limit and of the pitch limit -- read by the fp32-evaluation variants only, so
+    //                computed with the fp32 sincos (25 instructions; the fp64 ocml pair is ~1500 cycles on the path every
+    //                wave of the workgroup waits for) and skipped in the fp64 kernels
     static constexpr int FD_ND_LANES = 7;
+    template <bool FAST>
     static FD_DEV void derive_lane(int lane, const double* __restrict__ src, double* blk)
     {
         if (lane < 5) {
             const int from = lane == 0 ? FD_P_MASS : (lane == 1 ? FD_P_IXX : (lane == 2 ? FD_P_IYY : (lane == 3 ? FD_P_IZZ : FD_P_THRUST_ZERO_VELOCITY)));
             const int to = lane == 0 ? FD_PD_INV_MASS : (lane == 1 ? FD_PD_INV_IXX : (lane == 2 ? FD_PD_INV_IYY : (lane == 3 ? FD_PD_INV_IZZ : FD_PD_INV_THRUST_ZERO_V)));
             blk[to] = 1.0 / src[from];
-        } else if (lane < FD_ND_LANES) {
+        } else if (FAST && lane < FD_ND_LANES) {
             const bool is_alpha = lane == 5;
             const double a = src[is_alpha ? FD_P_MAX_ALPHA_RAD : FD_P_MAX_PITCH_RAD];
-            double sn, cs;
-            ::sincos(a, &sn, &cs);
+            float snf, csf;
+            fast::sincos(float(a), snf, csf);
+            const double sn = snf, cs = csf;
             blk[is_alpha ? FD_PD_SIN_MAX_ALPHA : FD_PD_SIN_MAX_PITCH] = sn;
             blk[is_alpha ? FD_PD_COS_MAX_ALPHA : FD_PD_COS_MAX_PITCH] = cs;
             if (is_alpha) {
@@ -569,12 +589,82 @@ FD_DEV void post_step(const Limits<S>& Lm, S (&x)[FD_NX])
     }
 }
 
+// ----- the fp32-evaluation integrator state: fp32 copy of the stored state + carried trigonometry -------------------
+// Lives in registers across the sub-steps of a launch AND across the control steps of the cascade kernels, whose glue
+// (derived scalars, guidance) reads the same fp32 copy and the same sin / cos.
+struct FastRK {
+    float x0[FD_NX];        // fp32 copy of the stored state
+    Trig t0;                // sin / cos of x0[6..8], rotated incrementally
+    float d0;               // max |increment| t0 was last rotated by (> 0.125: the next user rebuilds it in full)
+    template <typename S> FD_DEV void init(const S (&x)[FD_NX])
+    {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) x0[i] = float(x[i]);
+        t0 = trig_of(x0[6], x0[7], x0[8]);
+        d0 = 0.0f;
+    }
+    FD_DEV void ensure_trig()
+    {
+        if (FD_UNLIKELY(!(d0 <= 0.125f))) { t0 = trig_of(x0[6], x0[7], x0[8]); d0 = 0.0f; }
+    }
+};
+
+// one RK4 step of `dt` in fp32 evaluation: the four stages and their weighted sum run entirely in fp32 from the fp32 copy of
+// the state; the storage type S sees ONE add per word per step (x += S(dt/6 * sum)) -- that add is what keeps the "mixed"
+// variant inside the 1e-4 gate.  The clamps / wraps of :256-291 are tested on the fp32 copy with one combined predicate and
+// the (rare) fix-up runs under a wave-level branch.
+template <typename S>
+FD_DEV void rk4_fast_step(const Params<float>& P, const Limits<S>& Lm, const Controls<float>& C, S (&x)[FD_NX], FastRK& f,
+                          float hdt, float fdt, float dt6)
+{
+    using T = float;
+    // position (0..2) feeds nothing back, and roll / yaw enter only through their sin / cos: the stage states carry velocity,
+    // angles (for the rare full rebuild and the +-85 deg guard) and rates; the trigonometry is rotated
+    T xt[FD_NX], k[FD_NX], acc[FD_NX];
+    Trig tt;
+    dynamics_fast(P, C, f.x0, f.t0, f.d0, k);                            // k1
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = k[i];
+#pragma unroll
+    for (int i = 3; i < 12; ++i) xt[i] = __builtin_fmaf(hdt, k[i], f.x0[i]);
+    T dm = trig_rotate(f.t0, hdt * k[6], hdt * k[7], hdt * k[8], tt);
+    dynamics_fast(P, C, xt, tt, dm, k);                                  // k2
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = __builtin_fmaf(T(2), k[i], acc[i]);
+#pragma unroll
+    for (int i = 3; i < 12; ++i) xt[i] = __builtin_fmaf(hdt, k[i], f.x0[i]);
+    dm = trig_rotate(f.t0, hdt * k[6], hdt * k[7], hdt * k[8], tt);
+    dynamics_fast(P, C, xt, tt, dm, k);                                  // k3
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = __builtin_fmaf(T(2), k[i], acc[i]);
+#pragma unroll
+    for (int i = 3; i < 12; ++i) xt[i] = __builtin_fmaf(fdt, k[i], f.x0[i]);
+    dm = trig_rotate(f.t0, fdt * k[6], fdt * k[7], fdt * k[8], tt);
+    dynamics_fast(P, C, xt, tt, dm, k);                                  // k4
+    T inc[FD_NX];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { inc[i] = dt6 * (acc[i] + k[i]); x[i] += S(inc[i]); f.x0[i] = T(x[i]); }
+    f.d0 = trig_rotate(f.t0, inc[6], inc[7], inc[8], f.t0);
+    // one predicate for every clamp / wrap / guard of :256-291, evaluated on the fp32 copy
+    T sum = f.x0[0];
+#pragma unroll
+    for (int i = 1; i < 12; ++i) sum += f.x0[i];
+    const T vmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(f.x0[3]), __builtin_fabsf(f.x0[4])), __builtin_fabsf(f.x0[5]));
+    const T rmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(f.x0[9]), __builtin_fabsf(f.x0[10])), __builtin_fabsf(f.x0[11]));
+    const T amax = __builtin_fmaxf(__builtin_fabsf(f.x0[6]), __builtin_fabsf(f.x0[8]));
+    const bool fix = !(vmax <= T(Lm.max_vel)) | !(rmax <= T(Lm.max_rate)) | !(__builtin_fabsf(f.x0[7]) <= T(Lm.max_pitch)) |
+                     !(amax <= T(FD_PI)) | (f.x0[2] > T(0)) | !M<T>::finite(sum);
+    if (FD_UNLIKELY(fix)) {
+        post_step<S, T>(Lm, x);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) f.x0[i] = T(x[i]);
+        f.d0 = T(1);                                             // the next user rebuilds the trigonometry in full
+    }
+}
+
 // ----- Simplified6DOF.step x n_sub: RK4 + post-clamps, simplified_6dof.py:247-291 ------------------------
 // fp64 evaluation (T = double): the reference's operation order, every clamp applied every step.
-// fp32 evaluation (T = float): the four stages and their weighted sum run entirely in fp32 from an fp32 copy of the
-//   state; the storage type S sees ONE add per word per step (x += S(dt/6 * sum)) -- that add is what keeps the
-//   "mixed" variant inside the 1e-4 gate.  The clamps/wraps are tested on the fp32 copy with one combined predicate
-//   and the (rare) fix-up runs under a wave-level branch.
+// fp32 evaluation (T = float): rk4_fast_step above.
 template <typename S, typename T>
 FD_DEV void rk4_substeps(const Params<T>& P, const Limits<S>& Lm, const Controls<T>& C, S (&x)[FD_NX], S dt, int n_sub)
 {
@@ -601,57 +691,10 @@ FD_DEV void rk4_substeps(const Params<T>& P, const Limits<S>& Lm, const Controls
             post_step<S, T>(Lm, x);
         }
     } else {
+        FastRK f;
+        f.init(x);                                               // the ONLY full sincos of the launch (rare blocks aside)
         const T hdt = T(S(0.5) * dt), fdt = T(dt), dt6 = T(dt / S(6));
-        const T max_vel = T(Lm.max_vel), max_pitch = T(Lm.max_pitch), max_rate = T(Lm.max_rate);
-        T x0[FD_NX];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) x0[i] = T(x[i]);
-        Trig t0 = trig_of(x0[6], x0[7], x0[8]);                  // the ONLY full sincos of the launch (rare blocks aside)
-        T d0 = T(0);                                             // max |increment| t0 was last rotated by
-        for (int s = 0; s < n_sub; ++s) {
-            // position (0..2) feeds nothing back, and roll / yaw enter only through their sin / cos: the stage states
-            // carry velocity, angles (for the rare full rebuild and the +-85 deg guard) and rates; the trigonometry is rotated
-            T xt[FD_NX], k[FD_NX], acc[FD_NX];
-            Trig tt;
-            dynamics_fast(P, C, x0, t0, d0, k);                                  // k1
-#pragma unroll
-            for (int i = 0; i < 12; ++i) acc[i] = k[i];
-#pragma unroll
-            for (int i = 3; i < 12; ++i) xt[i] = __builtin_fmaf(hdt, k[i], x0[i]);
-            T dm = trig_rotate(t0, hdt * k[6], hdt * k[7], hdt * k[8], tt);
-            dynamics_fast(P, C, xt, tt, dm, k);                                  // k2
-#pragma unroll
-            for (int i = 0; i < 12; ++i) acc[i] = __builtin_fmaf(T(2), k[i], acc[i]);
-#pragma unroll
-            for (int i = 3; i < 12; ++i) xt[i] = __builtin_fmaf(hdt, k[i], x0[i]);
-            dm = trig_rotate(t0, hdt * k[6], hdt * k[7], hdt * k[8], tt);
-            dynamics_fast(P, C, xt, tt, dm, k);                                  // k3
-#pragma unroll
-            for (int i = 0; i < 12; ++i) acc[i] = __builtin_fmaf(T(2), k[i], acc[i]);
-#pragma unroll
-            for (int i = 3; i < 12; ++i) xt[i] = __builtin_fmaf(fdt, k[i], x0[i]);
-            dm = trig_rotate(t0, fdt * k[6], fdt * k[7], fdt * k[8], tt);
-            dynamics_fast(P, C, xt, tt, dm, k);                                  // k4
-            T inc[FD_NX];
-#pragma unroll
-            for (int i = 0; i < 12; ++i) { inc[i] = dt6 * (acc[i] + k[i]); x[i] += S(inc[i]); x0[i] = T(x[i]); }
-            d0 = trig_rotate(t0, inc[6], inc[7], inc[8], t0);
-            // one predicate for every clamp / wrap / guard of :256-291, evaluated on the fp32 copy
-            T sum = x0[0];
-#pragma unroll
-            for (int i = 1; i < 12; ++i) sum += x0[i];
-            const T vmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(x0[3]), __builtin_fabsf(x0[4])), __builtin_fabsf(x0[5]));
-            const T rmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(x0[9]), __builtin_fabsf(x0[10])), __builtin_fabsf(x0[11]));
-            const T amax = __builtin_fmaxf(__builtin_fabsf(x0[6]), __builtin_fabsf(x0[8]));
-            const bool fix = !(vmax <= max_vel) | !(rmax <= max_rate) | !(__builtin_fabsf(x0[7]) <= max_pitch) |
-                             !(amax <= T(FD_PI)) | (x0[2] > T(0)) | !M<T>::finite(sum);
-            if (FD_UNLIKELY(fix)) {
-                post_step<S, T>(Lm, x);
-#pragma unroll
-                for (int i = 0; i < 12; ++i) x0[i] = T(x[i]);
-                d0 = T(1);                                       // the next k1 rebuilds the trigonometry in full
-            }
-        }
+        for (int s = 0; s < n_sub; ++s) rk4_fast_step<S>(P, Lm, C, x, f, hdt, fdt, dt6);
     }
 }
 
@@ -671,6 +714,24 @@ template <typename S> FD_DEV Derived<S> derived(const S (&x)[FD_NX])
     const S ve = (cth * spsi) * u + (sphi * sth * spsi + cphi * cpsi) * v + (cphi * sth * spsi - sphi * cpsi) * w;
     d.heading = M<S>::atan2(ve, vn);
     d.ground_speed = M<S>::sqrt(vn * vn + ve * ve);
+    return d;
+}
+// the same four scalars from the integrator's fp32 copy and its carried sin / cos (no sincos at all): the fp32-evaluation
+// cascade's glue.  v_NED = Rz(psi) [cth u + sth (sphi v + cphi w), cphi v - sphi w] as in dynamics_fast.
+FD_DEV Derived<float> derived_fast(FastRK& f)
+{
+    f.ensure_trig();
+    Derived<float> d;
+    const float u = f.x0[3], v = f.x0[4], w = f.x0[5];
+    const Trig& t = f.t0;
+    d.airspeed = fast::sqrt(__builtin_fmaf(u, u, __builtin_fmaf(v, v, w * w)));
+    d.altitude = -f.x0[2];
+    const float sv_cw = __builtin_fmaf(t.sphi, v, t.cphi * w);
+    const float ah = __builtin_fmaf(t.cth, u, t.sth * sv_cw);
+    const float bh = __builtin_fmaf(t.cphi, v, -(t.sphi * w));
+    const float vn = __builtin_fmaf(t.cpsi, ah, -(t.spsi * bh)), ve = __builtin_fmaf(t.spsi, ah, t.cpsi * bh);
+    d.heading = fast::atan2(ve, vn);
+    d.ground_speed = fast::sqrt(__builtin_fmaf(vn, vn, ve * ve));
     return d;
 }
 // airspeed / altitude only (what the env needs every step)
@@ -707,6 +768,32 @@ FD_DEV float pid_compute(const PidCfg& c, PidState& s, float setpoint, float mea
     return out;
 }
 
+// The same controller for the fp32-evaluation cascade (glue type float): FMA contraction allowed, v_med3 clamps, one
+// reciprocal of dt per launch instead of nine IEEE divisions per control step (~35 -> ~13 VALU per PID, none of the
+// v_cmp -> v_cndmask hazard pairs).  Its inputs already carry fp32 rounding of the state, so it differs from the bit-faithful
+// form by the same order (an ulp of the output); the fp64 parity variant, the fused rate-PID demonstrator of the env kernel
+// and fdyn_pid_compute_batch keep pid_compute.
+FD_DEV float pid_compute_fast(const PidCfg& c, PidState& s, float setpoint, float measurement, float dt, float inv_dt)
+{
+    const float error = setpoint - measurement;
+    const float integral = clipf(__builtin_fmaf(error, dt, s.integral), c.int_min, c.int_max);
+    const float derivative = (error - s.err_prev) * inv_dt;                  // inv_dt = 0 when dt <= 1e-6 (pid_controller.cpp:41)
+    const float dfilt = __builtin_fmaf(c.alpha, derivative, (1.0f - c.alpha) * s.dfilt);
+    const float out = clipf(__builtin_fmaf(c.kp, error, __builtin_fmaf(c.ki, integral, c.kd * dfilt)), c.out_min, c.out_max);
+    s.integral = integral; s.err_prev = error; s.dfilt = dfilt;
+    return out;
+}
+// dispatch on the glue type: double -> bit-faithful, float -> contracted
+template <typename G> struct PidDt {
+    float dt, inv_dt;
+    FD_DEV explicit PidDt(G d) : dt(float(d)), inv_dt(float(d) > 1e-6f ? fast::rcp(float(d)) : 0.0f) {}
+    FD_DEV float run(const PidCfg& c, PidState& s, float sp, float meas) const
+    {
+        if constexpr (sizeof(G) == 8) return pid_compute(c, s, sp, meas, dt);
+        else return pid_compute_fast(c, s, sp, meas, dt, inv_dt);
+    }
+};
+
 FD_DEV PidCfg load_pid_cfg(const float* t, int which)
 {
     const float* r = t + which * FD_NPC;
@@ -728,10 +815,10 @@ FD_DEV Surfaces<G> rate_agent(const PidCfg* cfg, PidState* st, const G* C, G p_c
     p_cmd = clipv(p_cmd, -C[FD_C_MAX_ROLL_RATE], C[FD_C_MAX_ROLL_RATE]);
     q_cmd = clipv(q_cmd, -C[FD_C_MAX_PITCH_RATE], C[FD_C_MAX_PITCH_RATE]);
     r_cmd = clipv(r_cmd, -C[FD_C_MAX_YAW_RATE], C[FD_C_MAX_YAW_RATE]);
-    const float fdt = float(dt);
-    const float o_roll = pid_compute(cfg[FD_PID_RATE_ROLL], st[FD_PID_RATE_ROLL], float(p_cmd), float(x[9]), fdt);
-    const float o_pitch = pid_compute(cfg[FD_PID_RATE_PITCH], st[FD_PID_RATE_PITCH], float(q_cmd), float(x[10]), fdt);
-    const float o_yaw = pid_compute(cfg[FD_PID_RATE_YAW], st[FD_PID_RATE_YAW], float(r_cmd), float(x[11]), fdt);
+    const PidDt<G> pd(dt);
+    const float o_roll = pd.run(cfg[FD_PID_RATE_ROLL], st[FD_PID_RATE_ROLL], float(p_cmd), float(x[9]));
+    const float o_pitch = pd.run(cfg[FD_PID_RATE_PITCH], st[FD_PID_RATE_PITCH], float(q_cmd), float(x[10]));
+    const float o_yaw = pd.run(cfg[FD_PID_RATE_YAW], st[FD_PID_RATE_YAW], float(r_cmd), float(x[11]));
     Surfaces<G> s;
     s.aileron = clipv(G(o_roll), G(-1), G(1));
     s.elevator = clipv(-G(o_pitch), G(-1), G(1));      // INVERTED (rate_agent.py:111-112)
@@ -749,10 +836,10 @@ FD_DEV Surfaces<G> attitude_agent(const PidCfg* cfg, PidState* st, const G* C, G
     pitch_cmd = clipv(pitch_cmd, -C[FD_C_MAX_PITCH], C[FD_C_MAX_PITCH]);
     yaw_cmd = has_yaw ? wrap_angle<G>(yaw_cmd) : G(0);
     const G cur_yaw = wrap_angle<G>(x[8]);
-    const float fdt = float(dt);
-    const float o_r = pid_compute(cfg[FD_PID_ATT_ROLL], st[FD_PID_ATT_ROLL], float(roll_cmd), float(x[6]), fdt);
-    const float o_p = pid_compute(cfg[FD_PID_ATT_PITCH], st[FD_PID_ATT_PITCH], float(pitch_cmd), float(x[7]), fdt);
-    const float o_y = pid_compute(cfg[FD_PID_ATT_YAW], st[FD_PID_ATT_YAW], float(yaw_cmd), float(cur_yaw), fdt);
+    const PidDt<G> pd(dt);
+    const float o_r = pd.run(cfg[FD_PID_ATT_ROLL], st[FD_PID_ATT_ROLL], float(roll_cmd), float(x[6]));
+    const float o_p = pd.run(cfg[FD_PID_ATT_PITCH], st[FD_PID_ATT_PITCH], float(pitch_cmd), float(x[7]));
+    const float o_y = pd.run(cfg[FD_PID_ATT_YAW], st[FD_PID_ATT_YAW], float(yaw_cmd), float(cur_yaw));
     const G p_cmd = clipv(G(o_r), -C[FD_C_MAX_ROLL_RATE], C[FD_C_MAX_ROLL_RATE]);
     const G q_cmd = clipv(G(o_p), -C[FD_C_MAX_PITCH_RATE], C[FD_C_MAX_PITCH_RATE]);
     const G r_cmd = clipv(G(o_y), -C[FD_C_MAX_YAW_RATE], C[FD_C_MAX_YAW_RATE]);
@@ -766,8 +853,8 @@ FD_DEV Surfaces<G> hsa_agent(const PidCfg* cfg, PidState* st, const G* C, G head
 {
     const G heading_error = wrap_angle<G>(heading_cmd - d.heading);
     const G virtual_setpoint = d.heading + heading_error;
-    const float fdt = float(dt);
-    G roll_angle = G(pid_compute(cfg[FD_PID_HEADING], st[FD_PID_HEADING], float(virtual_setpoint), float(d.heading), fdt));
+    const PidDt<G> pd(dt);
+    G roll_angle = G(pd.run(cfg[FD_PID_HEADING], st[FD_PID_HEADING], float(virtual_setpoint), float(d.heading)));
     roll_angle = clipv(roll_angle, -C[FD_C_MAX_BANK_RAD], C[FD_C_MAX_BANK_RAD]);
 
     const G g = G(9.81), h = d.altitude, V = d.airspeed;                     // :173-185
@@ -776,13 +863,15 @@ FD_DEV Surfaces<G> hsa_agent(const PidCfg* cfg, PidState* st, const G* C, G head
     const G E_balance = g * h - G(0.5) * (V * V);
     const G E_balance_cmd = g * altitude_cmd - G(0.5) * (speed_cmd * speed_cmd);
 
-    const G thr_adj = G(pid_compute(cfg[FD_PID_ENERGY], st[FD_PID_ENERGY], float(E_specific_cmd), float(E_specific), fdt));
+    const G thr_adj = G(pd.run(cfg[FD_PID_ENERGY], st[FD_PID_ENERGY], float(E_specific_cmd), float(E_specific)));
     G throttle = clipv(C[FD_C_BASELINE_THROTTLE] + thr_adj, G(0), G(1));
 
-    G pitch_angle = G(pid_compute(cfg[FD_PID_BALANCE], st[FD_PID_BALANCE], float(E_balance_cmd), float(E_balance), fdt));
-    const G cos_roll = M<G>::cos(roll_angle);                                // :205-208
+    G pitch_angle = G(pd.run(cfg[FD_PID_BALANCE], st[FD_PID_BALANCE], float(E_balance_cmd), float(E_balance)));
+    G cos_roll;                                                              // :205-208
+    if constexpr (sizeof(G) == 8) cos_roll = M<G>::cos(roll_angle);
+    else cos_roll = fast::cos_bounded(roll_angle);
     if (M<G>::abs(cos_roll) > G(0.01)) {
-        const G load_factor = G(1) / cos_roll;
+        const G load_factor = fdiv(G(1), cos_roll);
         pitch_angle += C[FD_C_LOAD_FACTOR_GAIN] * (load_factor - G(1));
     }
     pitch_angle = clipv(pitch_angle, -C[FD_C_MAX_PITCH_CMD_RAD], C[FD_C_MAX_PITCH_CMD_RAD]);
@@ -791,9 +880,13 @@ FD_DEV Surfaces<G> hsa_agent(const PidCfg* cfg, PidState* st, const G* C, G head
 
 template <typename G> FD_DEV G wrap_pi(G a)
 {   // np.arctan2(np.sin(a), np.cos(a))
-    G s, c;
-    M<G>::sincos(a, s, c);
-    return M<G>::atan2(s, c);
+    if constexpr (sizeof(G) == 4) {
+        return __builtin_fmaf(-6.2831853071795865f, __builtin_rintf(a * 0.15915494309189535f), a);
+    } else {
+        G s, c;
+        M<G>::sincos(a, s, c);
+        return M<G>::atan2(s, c);
+    }
 }
 
 // controllers/waypoint_agent.py:107-242 ; wp = {north, east, altitude, speed}
@@ -808,7 +901,9 @@ FD_DEV Surfaces<G> waypoint_agent(const PidCfg* cfg, PidState* st, const G* C, c
     G heading_cmd = los;
     if (gtype == FD_GUIDANCE_LOS) {                                          // :118-144
         const G V = pymax(d.airspeed, G(10));
-        const G turn_radius = (V * V) / (G(9.81) * M<G>::tan(C[FD_C_LOS_MAX_BANK_RAD]));
+        G turn_radius;
+        if constexpr (sizeof(G) == 8) turn_radius = (V * V) / (G(9.81) * M<G>::tan(C[FD_C_LOS_MAX_BANK_RAD]));
+        else turn_radius = (V * V) * C[FD_CD_LOS_INV_G_TAN_BANK];
         const G heading_error = wrap_pi<G>(heading_cmd - d.heading);
         const G anticipation = turn_radius * M<G>::abs(heading_error) / deg2rad<G>(90.0);
         if (hd < anticipation && M<G>::abs(heading_error) > deg2rad<G>(20.0)) {
@@ -817,14 +912,18 @@ FD_DEV Surfaces<G> waypoint_agent(const PidCfg* cfg, PidState* st, const G* C, c
         }
     } else if (gtype == FD_GUIDANCE_PP) {                                    // :146-178
         const G V = pymax(d.airspeed, G(10));
-        const G turn_radius = (V * V) / (G(9.81) * M<G>::tan(C[FD_C_WP_MAX_BANK_RAD]));
+        G turn_radius;
+        if constexpr (sizeof(G) == 8) turn_radius = (V * V) / (G(9.81) * M<G>::tan(C[FD_C_WP_MAX_BANK_RAD]));
+        else turn_radius = (V * V) * C[FD_CD_WP_INV_G_TAN_BANK];
         G lookahead = C[FD_C_LOOKAHEAD_TIME] * V;
         const G proximity = C[FD_C_PROXIMITY_SCALE] * turn_radius;
         if (hd < proximity) lookahead *= G(0.6) + G(0.4) * (hd / proximity);
         lookahead = clipv(lookahead, C[FD_C_LOOKAHEAD_MIN], C[FD_C_LOOKAHEAD_MAX]);
         if (hd > G(1)) {
             const G eff = pymin(lookahead, hd);
-            heading_cmd = M<G>::atan2((e1 / hd) * eff, (e0 / hd) * eff);
+            // fp64: the reference's own expression.  fp32 glue: atan2 of (e1, e0) scaled by the positive eff / hd IS the
+            // line-of-sight angle already in heading_cmd (the carrot lies on the LOS) -- no second atan2, no divisions
+            if constexpr (sizeof(G) == 8) heading_cmd = M<G>::atan2((e1 / hd) * eff, (e0 / hd) * eff);
         }
     }
     heading_cmd = wrap_pi<G>(heading_cmd);                                   // :185

@@ -32,9 +32,11 @@ __device__ __forceinline__ void stage(T* dst, const T* __restrict__ src, int n)
     for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
 }
 
-// Parameter blocks -> LDS: the FD_NP_USED caller words are copied; meanwhile FD_ND_LANES threads per aircraft type fill the
-// block's derived words (reciprocals, sin / cos of the alpha and pitch limits) straight from global memory, one word per
-// lane.  One barrier (the caller's).
+// Parameter blocks -> LDS: the FD_NP_USED caller words are copied; meanwhile a few threads per aircraft type fill the block's
+// derived words straight from global memory, one word per lane (Params::derive_lane).  One barrier (the caller's).  Kernels
+// issue their per-aircraft global loads BEFORE calling this, so the HBM round trip of the state overlaps the staging chain
+// (global -> LDS -> barrier -> LDS -> registers) instead of following it.
+template <bool FAST>
 __device__ __forceinline__ void stage_params(double* s_params, const double* __restrict__ params, int n_types)
 {
     for (int i = threadIdx.x; i < n_types * FD_NP_USED; i += blockDim.x) {
@@ -44,7 +46,18 @@ __device__ __forceinline__ void stage_params(double* s_params, const double* __r
     constexpr int NDL = Params<double>::FD_ND_LANES;
     if (int(threadIdx.x) < n_types * NDL) {
         const int t = threadIdx.x / NDL;
-        Params<double>::derive_lane(threadIdx.x - t * NDL, params + t * FD_NP, s_params + t * FD_NP_STAGED);
+        Params<double>::derive_lane<FAST>(threadIdx.x - t * NDL, params + t * FD_NP, s_params + t * FD_NP_STAGED);
+    }
+}
+
+// Cascade constants -> LDS in the glue type, plus the two derived reciprocals the fp32 guidance uses
+template <typename G>
+__device__ __forceinline__ void stage_cascade_consts(G* s_consts, const double* __restrict__ consts)
+{
+    for (int k = threadIdx.x; k < FD_NC; k += blockDim.x) s_consts[k] = G(consts[k]);
+    if (threadIdx.x < 2) {
+        const double bank = consts[threadIdx.x == 0 ? FD_C_WP_MAX_BANK_RAD : FD_C_LOS_MAX_BANK_RAD];
+        s_consts[FD_CD_WP_INV_G_TAN_BANK + threadIdx.x] = G(1.0 / (9.81 * ::tan(bank)));
     }
 }
 
@@ -79,20 +92,26 @@ sixdof_step_kernel(S* __restrict__ xs, const S* __restrict__ us, const uint8_t* 
                    S* __restrict__ derived_out)
 {
     __shared__ double s_params[FD_MAX_TYPES * FD_NP_STAGED];
-    stage_params(s_params, params, n_types);
-    __syncthreads();
     const LaneMap lm = lane_map(n);
     const int64_t i = lm.i;
+    S x[FD_NX], uc[FD_NU];
+    int ty = 0;
+    if (lm.on) {                                             // state / control loads in flight during the parameter staging
+#pragma unroll
+        for (int k = 0; k < FD_NX; ++k) x[k] = xs[k * n + i];
+#pragma unroll
+        for (int k = 0; k < FD_NU; ++k) uc[k] = us[k * n + i];
+        ty = lane_type(type, i, n_types);
+    }
+    stage_params<sizeof(T) == 4>(s_params, params, n_types);
+    __syncthreads();
     if (!lm.on) return;
 
-    const double* blk = s_params + lane_type(type, i, n_types) * FD_NP_STAGED;
+    const double* blk = s_params + ty * FD_NP_STAGED;
     Params<T> P; P.load(blk);
     Limits<S> Lm; Lm.load(blk);
-    S x[FD_NX];
-#pragma unroll
-    for (int k = 0; k < FD_NX; ++k) x[k] = xs[k * n + i];
     Controls<T> C;
-    C.set(P, us[FD_U_ELEVATOR * n + i], us[FD_U_AILERON * n + i], us[FD_U_RUDDER * n + i], us[FD_U_THROTTLE * n + i]);
+    C.set(P, uc[FD_U_ELEVATOR], uc[FD_U_AILERON], uc[FD_U_RUDDER], uc[FD_U_THROTTLE]);
 
     rk4_substeps<S, T>(P, Lm, C, x, dt_sub, n_sub);
 
@@ -146,54 +165,87 @@ pid_batch_kernel(const float* __restrict__ cfg /*[8] shared or [n][8]*/, int cfg
 // K1+K2: n_steps control steps of the 5-level cascade + one RK4 each
 //        (examples/03_waypoint_square_demo.py:148-209 per aircraft; agents in fdyn_core.hpp)
 // ---------------------------------------------------------------------------------------------------------
+// Glue type of the agents: the storage type for the fp64 parity variant, the COMPUTE type for the fp32-evaluation variants
+// (their PIDs take fp32 inputs anyway; round 1 ran the glue in fp64 -- ocml sincos / atan2 / fmod several times per control
+// step -- and the glue cost more than the physics: 7.3 us per control step of which 3.1 us were the RK4).
+template <typename S, typename T> struct GlueOf { using type = S; };
+template <typename S> struct GlueOf<S, float> { using type = float; };
+
+// (FD_BLOCK, 1): nine PID configurations, 27 PID states, the constants and the integrator state are ~250 live registers;
+// under the default occupancy target the allocator parked part of them in AGPRs and paid ~80 v_accvgpr moves per control step
 template <typename S, typename T>
-__global__ void __launch_bounds__(FD_BLOCK)
+__global__ void __launch_bounds__(FD_BLOCK, 1)
 cascade_step_kernel(S* __restrict__ xs, float* __restrict__ pid_state /*[9*3][n]*/, int32_t* __restrict__ wp_idx,
                     const uint8_t* __restrict__ type, const double* __restrict__ params, int n_types,
                     const float* __restrict__ pid_cfg /*[9][8]*/, const double* __restrict__ consts /*[FD_NC]*/,
                     const double* __restrict__ wps /*[n_wp][4]*/, int n_wp, int64_t n, S dt, int n_steps,
                     S* __restrict__ surf_out /*[4][n] or null*/, int32_t* __restrict__ reached_total /*[n] or null*/)
 {
+    using G = typename GlueOf<S, T>::type;
+    constexpr bool FAST = sizeof(T) == 4;
     __shared__ double s_params[FD_MAX_TYPES * FD_NP_STAGED];
     __shared__ float s_pid_cfg[FD_NPID * FD_NPC];
-    __shared__ S s_consts[FD_NC];
-    __shared__ S s_wps[FD_MAX_WAYPOINTS * FD_NWP];
-    stage_params(s_params, params, n_types);
-    stage(s_pid_cfg, pid_cfg, FD_NPID * FD_NPC);
-    for (int k = threadIdx.x; k < FD_NC; k += blockDim.x) s_consts[k] = S(consts[k]);
-    for (int k = threadIdx.x; k < n_wp * FD_NWP; k += blockDim.x) s_wps[k] = S(wps[k]);
-    __syncthreads();
+    __shared__ G s_consts[FD_NC_STAGED];
+    __shared__ G s_wps[FD_MAX_WAYPOINTS * FD_NWP];
     const LaneMap lm = lane_map(n);
     const int64_t i = lm.i;
+    PidState st[FD_NPID];
+    S x[FD_NX];
+    int32_t idx = 0;
+    int ty = 0;
+    if (lm.on) {                                             // per-aircraft loads in flight during the staging below
+#pragma unroll
+        for (int k = 0; k < FD_NPID; ++k)
+            st[k] = PidState{ pid_state[(k * FD_NPS + FD_PS_INTEGRAL) * n + i], pid_state[(k * FD_NPS + FD_PS_ERR_PREV) * n + i],
+                              pid_state[(k * FD_NPS + FD_PS_DFILT) * n + i] };
+#pragma unroll
+        for (int k = 0; k < FD_NX; ++k) x[k] = xs[k * n + i];
+        idx = wp_idx[i];
+        ty = lane_type(type, i, n_types);
+    }
+    stage_params<FAST>(s_params, params, n_types);
+    stage(s_pid_cfg, pid_cfg, FD_NPID * FD_NPC);
+    stage_cascade_consts<G>(s_consts, consts);
+    for (int k = threadIdx.x; k < n_wp * FD_NWP; k += blockDim.x) s_wps[k] = G(wps[k]);
+    __syncthreads();
     if (!lm.on) return;
 
-    const double* blk = s_params + lane_type(type, i, n_types) * FD_NP_STAGED;
+    const double* blk = s_params + ty * FD_NP_STAGED;
     Params<T> P; P.load(blk);
     Limits<S> Lm; Lm.load(blk);
     PidCfg cfg[FD_NPID];
-    PidState st[FD_NPID];
 #pragma unroll
-    for (int k = 0; k < FD_NPID; ++k) {
-        cfg[k] = load_pid_cfg(s_pid_cfg, k);
-        st[k] = PidState{ pid_state[(k * FD_NPS + FD_PS_INTEGRAL) * n + i], pid_state[(k * FD_NPS + FD_PS_ERR_PREV) * n + i],
-                          pid_state[(k * FD_NPS + FD_PS_DFILT) * n + i] };
-    }
-    S x[FD_NX];
+    for (int k = 0; k < FD_NPID; ++k) cfg[k] = load_pid_cfg(s_pid_cfg, k);
+    G Cr[FD_NC_STAGED];                                      // cascade constants in registers: read once, not once per control step
 #pragma unroll
-    for (int k = 0; k < FD_NX; ++k) x[k] = xs[k * n + i];
-    int32_t idx = wp_idx[i];
+    for (int k = 0; k < FD_NC_STAGED; ++k) Cr[k] = s_consts[k];
     int32_t reached = 0;
-    const bool restart = int(s_consts[FD_C_ON_COMPLETE]) == 1;
-    Surfaces<S> surf{ S(0), S(0), S(0), S(0) };
+    const bool restart = int(Cr[FD_C_ON_COMPLETE]) == 1;
+    Surfaces<G> surf{ G(0), G(0), G(0), G(0) };
 
-    for (int s = 0; s < n_steps; ++s) {
-        if (idx < n_wp && waypoint_reached<S>(s_consts, s_wps + idx * FD_NWP, x)) { idx += 1; reached += 1; }   // mission.update
-        if (idx >= n_wp) { if (restart) idx = 0; else break; }              // COMPLETE: freeze this aircraft
-        const Derived<S> d = derived<S>(x);
-        surf = waypoint_agent<S>(cfg, st, s_consts, s_wps + idx * FD_NWP, x, d, dt);
-        Controls<T> C;
-        C.set(P, surf.elevator, surf.aileron, surf.rudder, surf.throttle);
-        rk4_substeps<S, T>(P, Lm, C, x, dt, 1);
+    if constexpr (FAST) {
+        FastRK f;
+        f.init(x);
+        const float hdt = float(S(0.5) * dt), fdt = float(dt), dt6 = float(dt / S(6));
+        for (int s = 0; s < n_steps; ++s) {
+            if (idx < n_wp && waypoint_reached<G>(Cr, s_wps + idx * FD_NWP, f.x0)) { idx += 1; reached += 1; }   // mission.update
+            if (idx >= n_wp) { if (restart) idx = 0; else break; }          // COMPLETE: freeze this aircraft
+            const Derived<G> d = derived_fast(f);
+            surf = waypoint_agent<G>(cfg, st, Cr, s_wps + idx * FD_NWP, f.x0, d, fdt);
+            Controls<T> C;
+            C.set(P, surf.elevator, surf.aileron, surf.rudder, surf.throttle);
+            rk4_fast_step<S>(P, Lm, C, x, f, hdt, fdt, dt6);
+        }
+    } else {
+        for (int s = 0; s < n_steps; ++s) {
+            if (idx < n_wp && waypoint_reached<S>(Cr, s_wps + idx * FD_NWP, x)) { idx += 1; reached += 1; }   // mission.update
+            if (idx >= n_wp) { if (restart) idx = 0; else break; }          // COMPLETE: freeze this aircraft
+            const Derived<S> d = derived<S>(x);
+            surf = waypoint_agent<S>(cfg, st, Cr, s_wps + idx * FD_NWP, x, d, dt);
+            Controls<T> C;
+            C.set(P, surf.elevator, surf.aileron, surf.rudder, surf.throttle);
+            rk4_substeps<S, T>(P, Lm, C, x, dt, 1);
+        }
     }
 
 #pragma unroll
@@ -207,8 +259,8 @@ cascade_step_kernel(S* __restrict__ xs, float* __restrict__ pid_state /*[9*3][n]
     wp_idx[i] = idx;
     if (reached_total) reached_total[i] += reached;
     if (surf_out) {
-        surf_out[FD_U_ELEVATOR * n + i] = surf.elevator; surf_out[FD_U_AILERON * n + i] = surf.aileron;
-        surf_out[FD_U_RUDDER * n + i] = surf.rudder; surf_out[FD_U_THROTTLE * n + i] = surf.throttle;
+        surf_out[FD_U_ELEVATOR * n + i] = S(surf.elevator); surf_out[FD_U_AILERON * n + i] = S(surf.aileron);
+        surf_out[FD_U_RUDDER * n + i] = S(surf.rudder); surf_out[FD_U_THROTTLE * n + i] = S(surf.throttle);
     }
 }
 
@@ -221,18 +273,20 @@ cascade_step_kernel(S* __restrict__ xs, float* __restrict__ pid_state /*[9*3][n]
 //   FD_LEVEL_ATTITUDE roll, pitch, yaw (NaN = none), thr   FD_LEVEL_WAYPOINT  north, east, altitude, speed (NaN = keep)
 // ---------------------------------------------------------------------------------------------------------
 template <typename S, typename T>
-__global__ void __launch_bounds__(FD_BLOCK)
+__global__ void __launch_bounds__(FD_BLOCK, 1)
 agent_step_kernel(int level, S* __restrict__ xs, float* __restrict__ pid_state /*[9*3][n]*/, const uint8_t* __restrict__ type,
                   const double* __restrict__ params, int n_types, const float* __restrict__ pid_cfg,
                   const double* __restrict__ consts, const S* __restrict__ cmd /*[4][n]*/, int64_t n, S dt, int n_steps,
                   S* __restrict__ surf_out /*[4][n]*/, int cfg_per_lane /*pid_cfg is [n][9][8]: one gain set per aircraft*/)
 {
+    using G = typename GlueOf<S, T>::type;
+    constexpr bool FAST = sizeof(T) == 4;
     __shared__ double s_params[FD_MAX_TYPES * FD_NP_STAGED];
     __shared__ float s_pid_cfg[FD_NPID * FD_NPC];
-    __shared__ S s_consts[FD_NC];
-    stage_params(s_params, params, n_types);
+    __shared__ G s_consts[FD_NC_STAGED];
+    stage_params<FAST>(s_params, params, n_types);
     if (!cfg_per_lane) stage(s_pid_cfg, pid_cfg, FD_NPID * FD_NPC);
-    for (int k = threadIdx.x; k < FD_NC; k += blockDim.x) s_consts[k] = S(consts[k]);
+    stage_cascade_consts<G>(s_consts, consts);
     __syncthreads();
     const LaneMap lm = lane_map(n);
     const int64_t i = lm.i;
@@ -251,25 +305,44 @@ agent_step_kernel(int level, S* __restrict__ xs, float* __restrict__ pid_state /
     S x[FD_NX];
 #pragma unroll
     for (int k = 0; k < FD_NX; ++k) x[k] = xs[k * n + i];
-    const S c0 = cmd[i], c1 = cmd[n + i], c2 = cmd[2 * n + i], c3 = cmd[3 * n + i];
-    Surfaces<S> surf{ S(0), S(0), S(0), S(0) };
+    const G c0 = G(cmd[i]), c1 = G(cmd[n + i]), c2 = G(cmd[2 * n + i]), c3 = G(cmd[3 * n + i]);
+    Surfaces<G> surf{ G(0), G(0), G(0), G(0) };
     const int iters = n_steps > 0 ? n_steps : 1;
-    for (int s = 0; s < iters; ++s) {
+    const G gdt = G(dt);
+    // one agent call on the glue-typed state `xg` with its derived scalars `dd` (a callable so both precisions share the switch)
+    auto act = [&](const G (&xg)[FD_NX], auto&& derive) {
         if (level == FD_LEVEL_RATE) {
-            surf = rate_agent<S>(cfg, st, s_consts, c0, c1, c2, c3, x, dt);
+            surf = rate_agent<G>(cfg, st, s_consts, c0, c1, c2, c3, xg, gdt);
         } else if (level == FD_LEVEL_ATTITUDE) {
             const bool has_yaw = c2 == c2;
-            surf = attitude_agent<S>(cfg, st, s_consts, c0, c1, has_yaw ? c2 : S(0), has_yaw, c3, x, dt);
+            surf = attitude_agent<G>(cfg, st, s_consts, c0, c1, has_yaw ? c2 : G(0), has_yaw, c3, xg, gdt);
         } else if (level == FD_LEVEL_HSA) {
-            surf = hsa_agent<S>(cfg, st, s_consts, c0, c1, c2, x, derived<S>(x), dt);
+            surf = hsa_agent<G>(cfg, st, s_consts, c0, c1, c2, xg, derive(), gdt);
         } else {
-            const S wp[FD_NWP] = { c0, c1, c2, c3 };
-            surf = waypoint_agent<S>(cfg, st, s_consts, wp, x, derived<S>(x), dt);
+            const G wp[FD_NWP] = { c0, c1, c2, c3 };
+            surf = waypoint_agent<G>(cfg, st, s_consts, wp, xg, derive(), gdt);
         }
-        if (n_steps > 0) {
-            Controls<T> C;
-            C.set(P, surf.elevator, surf.aileron, surf.rudder, surf.throttle);
-            rk4_substeps<S, T>(P, Lm, C, x, dt, 1);
+    };
+    if constexpr (FAST) {
+        FastRK f;
+        f.init(x);
+        const float hdt = float(S(0.5) * dt), fdt = float(dt), dt6 = float(dt / S(6));
+        for (int s = 0; s < iters; ++s) {
+            act(f.x0, [&]() { return derived_fast(f); });
+            if (n_steps > 0) {
+                Controls<T> C;
+                C.set(P, surf.elevator, surf.aileron, surf.rudder, surf.throttle);
+                rk4_fast_step<S>(P, Lm, C, x, f, hdt, fdt, dt6);
+            }
+        }
+    } else {
+        for (int s = 0; s < iters; ++s) {
+            act(x, [&]() { return derived<S>(x); });
+            if (n_steps > 0) {
+                Controls<T> C;
+                C.set(P, surf.elevator, surf.aileron, surf.rudder, surf.throttle);
+                rk4_substeps<S, T>(P, Lm, C, x, dt, 1);
+            }
         }
     }
     if (n_steps > 0) {
@@ -283,8 +356,8 @@ agent_step_kernel(int level, S* __restrict__ xs, float* __restrict__ pid_state /
         pid_state[(k * FD_NPS + FD_PS_DFILT) * n + i] = st[k].dfilt;
     }
     if (surf_out) {
-        surf_out[FD_U_ELEVATOR * n + i] = surf.elevator; surf_out[FD_U_AILERON * n + i] = surf.aileron;
-        surf_out[FD_U_RUDDER * n + i] = surf.rudder; surf_out[FD_U_THROTTLE * n + i] = surf.throttle;
+        surf_out[FD_U_ELEVATOR * n + i] = S(surf.elevator); surf_out[FD_U_AILERON * n + i] = S(surf.aileron);
+        surf_out[FD_U_RUDDER * n + i] = S(surf.rudder); surf_out[FD_U_THROTTLE * n + i] = S(surf.throttle);
     }
 }
 
@@ -516,17 +589,6 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
     __shared__ float s_tile[FD_BLOCK / FD_WAVE][FD_WAVE * (FD_OBS_DIM + 1)];
     __shared__ float s_pid_cfg[3 * FD_NPC];
     __shared__ S s_consts[FD_NC];
-    stage_params(s_params, params, n_types);
-    // actions == null: the fused rate-PID demonstrator drives the env.  residual_scale > 0 (with actions AND pid state):
-    // ResidualRateControlEnv -- action = clip(PID + scale * residual) (residual_rate_env.py:99-157).
-    const bool residual_mode = actions != nullptr && residual_scale > 0.0f && pid_state != nullptr;
-    const bool pid_mode = actions == nullptr || residual_mode;
-    if (pid_mode) {
-        stage(s_pid_cfg, pid_cfg, 3 * FD_NPC);
-        for (int k = threadIdx.x; k < FD_NC; k += blockDim.x) s_consts[k] = S(casc_consts[k]);
-    }
-    __syncthreads();
-
     const LaneMap lm = lane_map(n);
     const int64_t i = lm.i;
     const int lane = lm.lane, wave = threadIdx.x / FD_WAVE;
@@ -534,6 +596,34 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
     EnvConsts<S> ec;
     load_env_consts<S>(EC, ec);
     const bool uses_sched = ec.cmd_type == FD_CMD_RAMP || ec.cmd_type == FD_CMD_SINE;
+    // actions == null: the fused rate-PID demonstrator drives the env.  residual_scale > 0 (with actions AND pid state):
+    // ResidualRateControlEnv -- action = clip(PID + scale * residual) (residual_rate_env.py:99-157).
+    const bool residual_mode = actions != nullptr && residual_scale > 0.0f && pid_state != nullptr;
+    const bool pid_mode = actions == nullptr || residual_mode;
+
+    // ---- every per-env global load is issued HERE, before the parameter staging and its barrier: the HBM round trip of
+    // the state overlaps the staging chain instead of following it
+    S x[FD_NX];
+    EnvState<S> e;
+    int32_t step = 0, episode = 0;
+    int ty = 0;
+    float4 av = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < FD_NX; ++k) x[k] = xs[k * n + i];
+        env_load<S>(e, es, n, i, uses_sched);
+        step = eis[FD_EI_STEP * n + i];
+        episode = eis[FD_EI_EPISODE * n + i];
+        if (actions) av = reinterpret_cast<const float4*>(actions)[i];
+        ty = lane_type(type, i, n_types);
+    }
+    stage_params<sizeof(T) == 4>(s_params, params, n_types);
+    if (pid_mode) {
+        stage(s_pid_cfg, pid_cfg, 3 * FD_NPC);
+        for (int k = threadIdx.x; k < FD_NC; k += blockDim.x) s_consts[k] = S(casc_consts[k]);
+    }
+    __syncthreads();
+
     // double-buffered event counters: this launch appends to ev_count[] and clears the OTHER set for the next
     // launch, so the per-step host-side memset disappears from the stream
     if (ev_count_next && blockIdx.x == 0 && threadIdx.x < FD_EV_SHARDS) ev_count_next[threadIdx.x] = 0;
@@ -542,26 +632,17 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
 #pragma unroll
     for (int k = 0; k < FD_OBS_DIM; ++k) o[k] = 0.0f;
     bool done = false, term = false;
-    S x[FD_NX];
-    EnvState<S> e;
     S reward = S(0);
-    int32_t step = 0, episode = 0;
 
     if (active) {
-        const double* blk = s_params + lane_type(type, i, n_types) * FD_NP_STAGED;
+        const double* blk = s_params + ty * FD_NP_STAGED;
         Params<T> P; P.load(blk);
         Limits<S> Lm; Lm.load(blk);
-#pragma unroll
-        for (int k = 0; k < FD_NX; ++k) x[k] = xs[k * n + i];
-        env_load<S>(e, es, n, i, uses_sched);
-        step = eis[FD_EI_STEP * n + i];
-        episode = eis[FD_EI_EPISODE * n + i];
 
         // ---- action: from the policy ([n][4] f32, one 16-B load per lane) or the fused rate PID -------------
         float a_in[4];
         S res_bonus = S(0);
         if (!pid_mode) {
-            const float4 av = reinterpret_cast<const float4*>(actions)[i];
             a_in[0] = av.x; a_in[1] = av.y; a_in[2] = av.z; a_in[3] = av.w;
         } else {                                         // learned_controllers/utils/pid_demonstrations.py:47-77
             PidCfg cfg[3]; PidState st[3];
@@ -580,8 +661,7 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
             }
             if (residual_mode) {                      // float32 arithmetic, as the reference's NumPy float32 arrays
 #pragma clang fp contract(off)
-                const float4 rv = reinterpret_cast<const float4*>(actions)[i];
-                const float rr[4] = { rv.x, rv.y, rv.z, rv.w };
+                const float rr[4] = { av.x, av.y, av.z, av.w };
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float c = a_in[k] + rr[k] * residual_scale;

@@ -78,7 +78,10 @@ enum {
      * residual_rate_env.py:113, 0.5 in eval_rate.py:196) and the dt it hands the PIDs (0 = the env dt, as
      * pid_demonstrations.py:66; eval_rate.py:200 passes none => ControllerConfig.rate_loop_dt, types.py:342) */
     FD_C_PID_THROTTLE, FD_C_PID_DT,
-    FD_NC = 28
+    FD_NC = 28,
+    /* derived, in the kernels' staged copy only: 1 / (g tan(bank limit)) of the two guidance laws (waypoint_agent.py:121,148) */
+    FD_CD_WP_INV_G_TAN_BANK = FD_NC, FD_CD_LOS_INV_G_TAN_BANK,
+    FD_NC_STAGED = 30
 };
 enum { FD_GUIDANCE_LOS = 0, FD_GUIDANCE_PP = 1, FD_GUIDANCE_DEFAULT = 2 };
 /* control levels, numbered as the reference's ControlMode (controllers/types.py:13-24): the level a command enters at */

@@ -1,0 +1,6 @@
+R=$GRAFT_REPO_ROOT
+cd $R
+timeout -k 10 1100 python -m pytest tests -x -q -m gpu > gpurun_out/r02_gpu_all.log 2>&1; echo "rc=$?" >> gpurun_out/r02_gpu_all.log
+bash scratch/prof_r02_kernels.sh cascade r02b_cascade > gpurun_out/prof_cascade.log 2>&1
+tail -n 4 gpurun_out/r02_gpu_all.log
+cut -c1-250 gpurun_out/prof_r02b_cascade/trace_bench.json
