@@ -113,6 +113,8 @@ def main(argv=None):
             config["environment"]["command_type"] = phase["command_type"]
             env = create_vec_env(config, n_envs=n_envs, seed=seed + rank * n_envs, precision=args.precision)
             model.set_env(env)
+            if callback is not None:                        # train_rate.py:163-167: callbacks rebuilt on the phase's task
+                callback = create_callbacks(config, previous=callback)
             if rank == 0:
                 print(f"=== phase {phase['name']}: {phase['difficulty']}/{phase['command_type']} {phase['timesteps']} steps")
             model.learn(int(phase["timesteps"] * args.timesteps_scale), log_interval=config["training"]["log_interval"],
@@ -125,7 +127,10 @@ def main(argv=None):
         os.makedirs(config["paths"]["model_save_dir"], exist_ok=True)
         model.save(os.path.join(config["paths"]["model_save_dir"], "final_model.pt"))
         model.save_sb3_zip(os.path.join(config["paths"]["model_save_dir"], "final_model"))   # train_rate.py:353-355 layout
-        print("final evaluation:", {k: v for k, v in run_final_evaluation(model).items() if k.startswith("mean")})
+        final = run_final_evaluation(model, difficulty=config["environment"]["difficulty"],
+                                     command_type=config["environment"]["command_type"])
+        print(f"final evaluation ({config['environment']['difficulty']}/{config['environment']['command_type']}):",
+              {k: v for k, v in final.items() if k.startswith("mean")})
     if world > 1:
         dist.destroy_process_group()
 

@@ -141,9 +141,13 @@ def load_demonstrations(path: str) -> Tuple[np.ndarray, np.ndarray]:
     return d["observations"], d["actions"]
 
 
-def run_final_evaluation(model, difficulty="hard", n_episodes=10, dt=0.02, seed=0, residual_scale=0.0):
-    """training_utils.py:216-249: deterministic policy, one episode per env, mean length and return."""
-    env = GpuRateVecEnv(n_episodes, difficulty, 10.0, dt, "step", seed=seed, precision="mixed", sampling="device",
+@torch.no_grad()
+def run_final_evaluation(model, difficulty="hard", n_episodes=10, dt=0.02, seed=0, residual_scale=0.0, command_type="step"):
+    """training_utils.py:216-249: deterministic policy, one episode per env, mean length and return.  Runs without autograd
+    (the same fused inference path the rollouts use; with grad enabled the policy would fall back to the un-fused cells and
+    build a 500-step graph through the recurrent state).  `command_type` as in the env: the periodic evaluation of a
+    curriculum phase flies that phase's command type (random-walk increments are drawn in-kernel)."""
+    env = GpuRateVecEnv(n_episodes, difficulty, 10.0, dt, command_type, seed=seed, precision="mixed", sampling="device",
                         residual_scale=residual_scale)
     obs = env.reset().clone()
     pol = model.policy
@@ -190,21 +194,31 @@ class EvalCallback:
     the best mean reward so far kept as `<best_model_save_path>/best_model.pt`."""
 
     def __init__(self, difficulty: str, best_model_save_path: str, log_path: str, eval_freq: int, n_eval_episodes: int = 10,
-                 deterministic: bool = True, residual_scale: float = 0.0, writer=None):
-        self.difficulty, self.best_dir, self.log_dir = difficulty, best_model_save_path, log_path
+                 deterministic: bool = True, residual_scale: float = 0.0, writer=None, command_type: str = "step",
+                 history=None):
+        self.difficulty, self.command_type = difficulty, command_type
+        self.best_dir, self.log_dir = best_model_save_path, log_path
         self.writer = writer                               # ProgressLogger: eval/mean_reward, eval/mean_ep_length
         self.residual_scale = residual_scale
         self.eval_freq, self.n_eval_episodes, self.deterministic = max(int(eval_freq), 1), n_eval_episodes, deterministic
-        self._last, self.best_mean_reward = 0, -float("inf")
-        self.timesteps, self.results, self.ep_lengths = [], [], []
+        self._start, self._last, self.best_mean_reward = None, 0, -float("inf")
+        # evaluation history: a curriculum rebuilds this callback per phase (fresh best-reward baseline, the phase's difficulty
+        # and command type -- train_rate.py:150-170); the history list can be handed on so evaluations.npz keeps every phase
+        self.timesteps, self.results, self.ep_lengths = history if history is not None else ([], [], [])
+
+    @property
+    def history(self):
+        return self.timesteps, self.results, self.ep_lengths
 
     def __call__(self, model, stats):
         n_calls = model.num_timesteps // model.env.num_envs
-        if n_calls // self.eval_freq <= self._last:
+        if self._start is None:                            # SB3 counts a callback's own calls: a phase starts at zero
+            self._start = n_calls - model.cfg.n_steps
+        if (n_calls - self._start) // self.eval_freq <= self._last:
             return
-        self._last = n_calls // self.eval_freq
+        self._last = (n_calls - self._start) // self.eval_freq
         ev = run_final_evaluation(model, difficulty=self.difficulty, n_episodes=self.n_eval_episodes,
-                                  residual_scale=self.residual_scale)
+                                  residual_scale=self.residual_scale, command_type=self.command_type)
         self.timesteps.append(model.num_timesteps); self.results.append(ev["rewards"]); self.ep_lengths.append(ev["lengths"])
         os.makedirs(self.log_dir, exist_ok=True)
         np.savez(os.path.join(self.log_dir, "evaluations.npz"), timesteps=np.array(self.timesteps),
@@ -273,17 +287,25 @@ class CallbackList:
             cb(model, stats)
 
 
-def create_callbacks(config: dict, eval_env=None, flight_logger=None) -> CallbackList:
+def create_callbacks(config: dict, eval_env=None, flight_logger=None, previous: Optional[CallbackList] = None) -> CallbackList:
     """training_utils.py:72-156: evaluation + checkpoint callbacks from the `paths` / `training` / `evaluation` sections.
+    The evaluation flies `environment.difficulty` / `environment.command_type` AS THEY ARE WHEN THIS IS CALLED: the curriculum
+    loop calls it once per phase after updating them, as the reference does (train_rate.py:150-170), so each phase is judged
+    on its own task with a fresh best-reward baseline.  `previous` (the callbacks of the phase before) hands on the ONE progress
+    logger / event file, the checkpoint schedule and the evaluation history.
     (`eval_env` is accepted for signature compatibility; evaluation builds its own device env.  The reference's optional
     TensorBoard flight-logging callback needs its tensorboard plugin, which is outside the hot path.)"""
     paths, tr, ev = config["paths"], config["training"], config.get("evaluation", {})
-    difficulty = config.get("environment", {}).get("difficulty", "medium")
-    progress = ProgressLogger(paths["tensorboard_log"])
+    env_cfg = config.get("environment", {})
+    prev = {type(c).__name__: c for c in (previous.callbacks if previous is not None else [])}
+    progress = prev.get("ProgressLogger") or ProgressLogger(paths["tensorboard_log"])
+    checkpoints = prev.get("CheckpointCallback") or CheckpointCallback(tr["save_freq"], paths["model_save_dir"], "rate_controller")
+    history = prev["EvalCallback"].history if "EvalCallback" in prev else None
     return CallbackList([
-        EvalCallback(difficulty, paths["best_model_path"], paths["best_model_path"], tr["eval_freq"],
-                     ev.get("n_eval_episodes", 10), ev.get("deterministic", True), writer=progress),
-        CheckpointCallback(tr["save_freq"], paths["model_save_dir"], "rate_controller"),
+        EvalCallback(env_cfg.get("difficulty", "medium"), paths["best_model_path"], paths["best_model_path"], tr["eval_freq"],
+                     ev.get("n_eval_episodes", 10), ev.get("deterministic", True), writer=progress,
+                     command_type=env_cfg.get("command_type", "step"), history=history),
+        checkpoints,
         progress])
 
 

@@ -263,6 +263,41 @@ def test_callbacks_checkpoints_best_model_and_resume(tmp_path):
     assert ck["num_timesteps"] == 6144 + 256 * 8 * 6
 
 
+def test_curriculum_rebuilds_the_callbacks_on_each_phase_task(tmp_path, monkeypatch):
+    """learned_controllers/train_rate.py:150-170: eval env and callbacks are recreated inside every curriculum phase, so the
+    periodic evaluation flies the phase's difficulty and command type and the best-reward baseline restarts; here one progress
+    logger and one evaluation history run through all phases."""
+    import yaml
+    from hcrl_amd import train_rate, training_utils as tu2
+    cfg = yaml.safe_load(open(train_rate.DEFAULT_CONFIG))
+    cfg["training"].update(n_envs=256, eval_freq=8, save_freq=1000)
+    cfg["ppo"].update(n_steps=8, n_epochs=1)
+    cfg["evaluation"]["n_eval_episodes"] = 4
+    cfg["curriculum"] = {"enabled": True, "phases": [
+        {"name": "a", "difficulty": "easy", "command_type": "step", "timesteps": 256 * 8 * 2},
+        {"name": "b", "difficulty": "hard", "command_type": "random", "timesteps": 256 * 8 * 2}]}
+    cfg["paths"] = {"model_save_dir": str(tmp_path / "ckpt"), "tensorboard_log": str(tmp_path / "tb"),
+                    "best_model_path": str(tmp_path / "best")}
+    p = tmp_path / "cfg.yaml"
+    p.write_text(yaml.safe_dump(cfg))
+    seen, real = [], tu2.run_final_evaluation
+
+    def spy(model, **kw):
+        seen.append((kw.get("difficulty"), kw.get("command_type"), int(model.num_timesteps)))
+        return real(model, **kw)
+
+    monkeypatch.setattr(tu2, "run_final_evaluation", spy)
+    monkeypatch.setattr(train_rate, "run_final_evaluation", spy)
+    train_rate.main(["--config", str(p), "--callbacks"])
+    assert seen == [("easy", "step", 2048), ("easy", "step", 4096), ("hard", "random", 6144), ("hard", "random", 8192),
+                    ("hard", "random", 8192)]                    # two periodic evaluations per phase + the final one
+    ev = np.load(tmp_path / "best" / "evaluations.npz")
+    assert list(ev["timesteps"]) == [2048, 4096, 6144, 8192]      # one history across the phases
+    import json
+    rows = [json.loads(l) for l in open(tmp_path / "tb" / "progress.jsonl")]
+    assert [r["timesteps"] for r in rows] == [2048 * k for k in range(1, 5)]     # ONE progress logger across the phases
+
+
 def test_gaussian_head_statistics_and_logprob():
     """Fused sampling head: z = (a - mean)/std must be ~N(0,1), log_prob must equal the closed form, and two successive
     calls (device-side step counter) must draw different noise."""
