@@ -953,34 +953,41 @@ template <typename G> struct EnvState {
 };
 
 // learned_controllers/envs/rewards.py:75-137 (weights :19-25) + SettlingTimeBonus :193-221
-template <typename G>
-FD_DEV G env_reward(EnvState<G>& e, const G (&err)[3], const G (&a)[4], G airspeed, G altitude, G roll, G pitch, G dt)
+// G = type of the carried env words, A = type the reward is COMPUTED in: A = G = double in the fp64 parity variant; A = float
+// in the fp32-evaluation variants (whose state already carries fp32-evaluation error: two fp64 ocml exp, a sqrt and half a
+// dozen IEEE divisions per env step bought nothing there).  The settling TIMER stays in G: `timer += dt; timer >= 0.2` is a
+// threshold on an accumulated sum (0.02 x 10 is 0.19999999999999998 in fp64, the reference fires one step later) and must
+// not move with the arithmetic type.
+template <typename G, typename A>
+FD_DEV A env_reward(EnvState<G>& e, const A (&err)[3], const A (&a)[4], A airspeed, A altitude, A roll, A pitch, G dt)
 {
-    const G tracking_error = (err[0] * err[0] + err[1] * err[1] + err[2] * err[2]) / G(3);
-    const G r_tracking = G(-0.5) * tracking_error;
-    const G d0 = a[0] - e.prev_action[0], d1 = a[1] - e.prev_action[1], d2 = a[2] - e.prev_action[2];
-    const G r_smooth = G(-0.01) * (d0 * d0 + (d1 * d1 + d2 * d2));
-    const G roll_st = M<G>::exp(-M<G>::abs(roll) / deg2rad<G>(45.0));
-    const G pitch_st = M<G>::exp(-M<G>::abs(pitch) / deg2rad<G>(30.0));
-    const G as_st = clipv((airspeed - G(8)) / G(12), G(0), G(1));
-    const G alt_st = clipv((altitude - G(10)) / G(90), G(0), G(1));
-    const G r_stab = G(0.3) * ((roll_st + pitch_st + as_st + alt_st) / G(4));
+    const A tracking_error = fdiv(err[0] * err[0] + err[1] * err[1] + err[2] * err[2], A(3));
+    const A r_tracking = A(-0.5) * tracking_error;
+    const A d0 = a[0] - A(e.prev_action[0]), d1 = a[1] - A(e.prev_action[1]), d2 = a[2] - A(e.prev_action[2]);
+    const A r_smooth = A(-0.01) * (d0 * d0 + (d1 * d1 + d2 * d2));
+    const A roll_st = M<A>::exp(fdiv(-M<A>::abs(roll), deg2rad<A>(45.0)));
+    const A pitch_st = M<A>::exp(fdiv(-M<A>::abs(pitch), deg2rad<A>(30.0)));
+    const A as_st = clipv(fdiv(airspeed - A(8), A(12)), A(0), A(1));
+    const A alt_st = clipv(fdiv(altitude - A(10), A(90)), A(0), A(1));
+    const A r_stab = A(0.3) * fdiv(roll_st + pitch_st + as_st + alt_st, A(4));
+    A sc[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const G pe = e.prev_err[i];
-        const bool flip = (signv(err[i]) != signv(pe)) && (M<G>::abs(pe) > G(0.01));
-        e.sign_changes[i] = G(0.9) * e.sign_changes[i] + (flip ? G(1) : G(0));
-        e.prev_err[i] = err[i];
+        const A pe = A(e.prev_err[i]);
+        const bool flip = (signv(err[i]) != signv(pe)) && (M<A>::abs(pe) > A(0.01));
+        sc[i] = A(0.9) * A(e.sign_changes[i]) + (flip ? A(1) : A(0));
+        e.sign_changes[i] = G(sc[i]);
+        e.prev_err[i] = G(err[i]);
     }
-    const G r_osc = G(-0.1) * (e.sign_changes[0] + (e.sign_changes[1] + e.sign_changes[2]));
-    G r = r_tracking + r_smooth + r_stab + r_osc + G(1);
+    const A r_osc = A(-0.1) * (sc[0] + (sc[1] + sc[2]));
+    A r = r_tracking + r_smooth + r_stab + r_osc + A(1);
 
     bool settled = true;                                                     // rewards.py:197-209
 #pragma unroll
-    for (int i = 0; i < 3; ++i) settled = settled && (M<G>::abs(err[i]) < pymax(M<G>::abs(e.cmd[i]) * G(0.05), G(0.05)));
+    for (int i = 0; i < 3; ++i) settled = settled && (M<A>::abs(err[i]) < pymax(M<A>::abs(A(e.cmd[i])) * A(0.05), A(0.05)));
     if (settled) {
         e.settle_timer += dt;
-        if (e.settle_timer >= G(0.2)) { e.is_settled = G(1); r += G(2) * dt; }
+        if (e.settle_timer >= G(0.2)) { e.is_settled = G(1); r += A(2) * A(dt); }
     } else {
         e.settle_timer = G(0);
         e.is_settled = G(0);
@@ -989,8 +996,8 @@ FD_DEV G env_reward(EnvState<G>& e, const G (&err)[3], const G (&a)[4], G airspe
 }
 
 // learned_controllers/envs/rate_env.py:374-408
-template <typename G>
-FD_DEV void env_observation(const G (&x)[FD_NX], const EnvState<G>& e, G airspeed, G altitude, float (&o)[FD_OBS_DIM])
+template <typename G, typename A = G>
+FD_DEV void env_observation(const G (&x)[FD_NX], const EnvState<G>& e, A airspeed, A altitude, float (&o)[FD_OBS_DIM])
 {
     o[0] = float(x[9]); o[1] = float(x[10]); o[2] = float(x[11]);
     o[3] = float(e.cmd[0]); o[4] = float(e.cmd[1]); o[5] = float(e.cmd[2]);

@@ -719,20 +719,24 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
         }
 
         // ---- reward, termination (rate_env.py:247-294,437-460) -------------------------------------------------
-        S airspeed, altitude;
-        airspeed_altitude<S>(x, airspeed, altitude);
-        const S err[3] = { e.cmd[0] - x[9], e.cmd[1] - x[10], e.cmd[2] - x[11] };
-        reward = env_reward<S>(e, err, a, airspeed, altitude, x[6], x[7], ec.dt);
+        // A = arithmetic type of the reward / observation glue: double in the fp64 parity variant, float where the
+        // derivatives are evaluated in fp32 anyway (env_reward's header says why the settling timer is exempt)
+        using A = typename GlueOf<S, T>::type;
+        const A u_ = A(x[3]), v_ = A(x[4]), w_ = A(x[5]), roll_ = A(x[6]), pitch_ = A(x[7]);
+        const A airspeed = M<A>::sqrt(u_ * u_ + v_ * v_ + w_ * w_), altitude = -A(x[2]);      // simplified_6dof.py:295-331
+        const A err[3] = { A(e.cmd[0]) - A(x[9]), A(e.cmd[1]) - A(x[10]), A(e.cmd[2]) - A(x[11]) };
+        const A aa[4] = { A(a[0]), A(a[1]), A(a[2]), A(a[3]) };
+        A rew = env_reward<S, A>(e, err, aa, airspeed, altitude, roll_, pitch_, ec.dt);
 #pragma unroll
         for (int k = 0; k < 4; ++k) e.prev_action[k] = a[k];                      // :282
-        term = (altitude < S(5)) || (M<S>::abs(x[6]) > deg2rad<S>(120.0)) || (M<S>::abs(x[7]) > deg2rad<S>(80.0)) ||
-               (airspeed < S(8));
+        term = (altitude < A(5)) || (M<A>::abs(roll_) > deg2rad<A>(120.0)) || (M<A>::abs(pitch_) > deg2rad<A>(80.0)) ||
+               (airspeed < A(8));
         const bool trunc = step >= ec.max_steps;
-        if (term && !trunc) reward += S(-100);                                    // :289-292
-        reward += res_bonus;
+        if (term && !trunc) rew += A(-100);                                       // :289-292
+        reward = S(rew) + res_bonus;
         e.ep_return += reward;
         done = term || trunc;
-        env_observation<S>(x, e, airspeed, altitude, o);
+        env_observation<S, A>(x, e, airspeed, altitude, o);
         if (reward_f32) reward_f32[i] = float(reward);
         if (reward_full) reward_full[i] = reward;
         terminated[i] = term ? 1 : 0;
