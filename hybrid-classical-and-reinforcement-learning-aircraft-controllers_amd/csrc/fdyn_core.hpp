@@ -961,6 +961,9 @@ template <typename G> struct EnvState {
 template <typename G, typename A>
 FD_DEV A env_reward(EnvState<G>& e, const A (&err)[3], const A (&a)[4], A airspeed, A altitude, A roll, A pitch, G dt)
 {
+    // no FMA contraction: the reference (NumPy) has none, and the two builds of the env kernel (register-capped or not) must
+    // return bit-identical rewards -- left to the backend, which products get fused depended on the register allocation
+#pragma clang fp contract(off)
     const A tracking_error = fdiv(err[0] * err[0] + err[1] * err[1] + err[2] * err[2], A(3));
     const A r_tracking = A(-0.5) * tracking_error;
     const A d0 = a[0] - A(e.prev_action[0]), d1 = a[1] - A(e.prev_action[1]), d2 = a[2] - A(e.prev_action[2]);
