@@ -397,7 +397,8 @@ def extras(args):
     # saturation throughput"): 4 Mi aircraft / 1 Mi envs per GPU -- what the hardware sustains once launch cost is amortised
     for key, wl_name, steps, warm, batch, prec in (
             ("env_f64", "env", 100, 10, None, "f64"), ("env_f32", "env", 200, 20, None, "f32"),
-            ("physics", "physics", 400, 40, None, None), ("cascade", "cascade", 100, 10, None, None),
+            ("physics", "physics", 400, 40, None, None), ("physics_f32", "physics", 400, 40, None, "f32"),
+            ("cascade", "cascade", 100, 10, None, None),
             ("rollout", "rollout", 60, 6, None, None),
             ("physics_20_substeps", "physics", 200, 20, None, None),
             ("physics_saturation", "physics", 100, 10, 1 << 22, None),
@@ -415,8 +416,9 @@ def extras(args):
             res[key] = {"value": wl.units_per_step * steps / wall, "ms_per_step": wall * 1e3 / steps,
                         "unit": "env-steps/s" if wl_name in ("rollout", "env") else "aircraft-steps/s",
                         "workload": wl.desc}
-            if key in ("env_f64", "env_f32"):
+            if prec is not None:
                 res[key]["precision"] = prec
+            if key in ("env_f64", "env_f32"):
                 res[key]["drift_vs_oracle"] = measured_drift(prec)
             if key == "rollout":
                 res[key]["policy"] = policy_block(wl, a, wall / steps, "rollout")

@@ -73,7 +73,7 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError here = header/library drift
             fn.restype, fn.argtypes = res, args
-        if lib.fdyn_abi_version() != 1:
+        if lib.fdyn_abi_version() != 2:
             raise FdynError("libfdyn_hip.so ABI version mismatch")
         _lib = lib
     return _lib

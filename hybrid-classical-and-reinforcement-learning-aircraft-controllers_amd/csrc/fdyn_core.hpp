@@ -957,9 +957,11 @@ template <typename G> struct EnvState {
 // in the fp32-evaluation variants (whose state already carries fp32-evaluation error: two fp64 ocml exp, a sqrt and half a
 // dozen IEEE divisions per env step bought nothing there).  The settling TIMER stays in G: `timer += dt; timer >= 0.2` is a
 // threshold on an accumulated sum (0.02 x 10 is 0.19999999999999998 in fp64, the reference fires one step later) and must
-// not move with the arithmetic type.
+// not move with the arithmetic type: fp64 env words accumulate seconds as the reference does, fp32 env words count steps
+// against `settle_steps` (the count at which the fp64 sum first reaches 0.2).
 template <typename G, typename A>
-FD_DEV A env_reward(EnvState<G>& e, const A (&err)[3], const A (&a)[4], A airspeed, A altitude, A roll, A pitch, G dt)
+FD_DEV A env_reward(EnvState<G>& e, const A (&err)[3], const A (&a)[4], A airspeed, A altitude, A roll, A pitch, double dt,
+                    int settle_steps)
 {
     // no FMA contraction: the reference (NumPy) has none, and the two builds of the env kernel (register-capped or not) must
     // return bit-identical rewards -- left to the backend, which products get fused depended on the register allocation
@@ -989,8 +991,13 @@ FD_DEV A env_reward(EnvState<G>& e, const A (&err)[3], const A (&a)[4], A airspe
 #pragma unroll
     for (int i = 0; i < 3; ++i) settled = settled && (M<A>::abs(err[i]) < pymax(M<A>::abs(A(e.cmd[i])) * A(0.05), A(0.05)));
     if (settled) {
-        e.settle_timer += dt;
-        if (e.settle_timer >= G(0.2)) { e.is_settled = G(1); r += A(2) * A(dt); }
+        if constexpr (sizeof(G) == 8) {
+            e.settle_timer += dt;
+            if (e.settle_timer >= G(0.2)) { e.is_settled = G(1); r += A(2) * A(dt); }
+        } else {                                       // fp32 env words: the timer word counts settled steps (exact in fp32)
+            e.settle_timer += G(1);
+            if (e.settle_timer >= G(settle_steps)) { e.is_settled = G(1); r += A(2) * A(dt); }
+        }
     } else {
         e.settle_timer = G(0);
         e.is_settled = G(0);
@@ -999,8 +1006,8 @@ FD_DEV A env_reward(EnvState<G>& e, const A (&err)[3], const A (&a)[4], A airspe
 }
 
 // learned_controllers/envs/rate_env.py:374-408
-template <typename G, typename A = G>
-FD_DEV void env_observation(const G (&x)[FD_NX], const EnvState<G>& e, A airspeed, A altitude, float (&o)[FD_OBS_DIM])
+template <typename G, typename A = G, typename E = G>
+FD_DEV void env_observation(const G (&x)[FD_NX], const EnvState<E>& e, A airspeed, A altitude, float (&o)[FD_OBS_DIM])
 {
     o[0] = float(x[9]); o[1] = float(x[10]); o[2] = float(x[11]);
     o[3] = float(e.cmd[0]); o[4] = float(e.cmd[1]); o[5] = float(e.cmd[2]);

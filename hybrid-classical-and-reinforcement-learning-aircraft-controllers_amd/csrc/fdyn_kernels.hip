@@ -168,6 +168,13 @@ pid_batch_kernel(const float* __restrict__ cfg /*[8] shared or [n][8]*/, int cfg
 // Glue type of the agents: the storage type for the fp64 parity variant, the COMPUTE type for the fp32-evaluation variants
 // (their PIDs take fp32 inputs anyway; round 1 ran the glue in fp64 -- ocml sincos / atan2 / fmod several times per control
 // step -- and the glue cost more than the physics: 7.3 us per control step of which 3.1 us were the RK4).
+// Storage type of the 21 env words (`e`): the state's storage type in the f64 and f32 variants, fp32 in `mixed` -- they are
+// commands, previous actions and reward-tracker state, computed in fp32 there anyway (GlueOf below); as fp64 rows they were
+// 272 of the 660 bytes an env step moves.  Two words are kept exact in fp32 form: the settling timer counts STEPS (fp32
+// holds small integers exactly; the threshold is the step count at which the reference's accumulated fp64 sum reaches 0.2 s)
+// and the episode time is step * dt rather than an accumulated fp32 sum.
+template <typename S, typename T> struct EnvOf { using type = S; };
+template <> struct EnvOf<double, float> { using type = float; };
 template <typename S, typename T> struct GlueOf { using type = S; };
 template <typename S> struct GlueOf<S, float> { using type = float; };
 
@@ -367,6 +374,7 @@ agent_step_kernel(int level, S* __restrict__ xs, float* __restrict__ pid_state /
 template <typename G> struct EnvConsts {
     G dt, mr0, mr1, mr2, scale;     // separate scalars: an indexed array here ends up in scratch
     int max_steps, cmd_type, n_sub;
+    int settle_steps;               // consecutive settled steps at which the reference's accumulated timer reaches 0.2 s
     // arithmetic select: a ?: chain over struct fields is turned back into an indexed (scratch) load by the compiler
     __device__ __forceinline__ G max_rate(int ax) const { return mr0 * G(ax == 0) + mr1 * G(ax == 1) + mr2 * G(ax == 2); }
 };
@@ -458,8 +466,8 @@ __device__ __forceinline__ void device_reset_record(uint64_t seed, uint32_t env,
 }
 
 // RateControlEnv.reset body (rate_env.py:170-204) from one record
-template <typename G>
-__device__ __forceinline__ void env_apply_reset(const G (&rec)[FD_NR], int cmd_type, G (&x)[FD_NX], EnvState<G>& e)
+template <typename G, typename E>
+__device__ __forceinline__ void env_apply_reset(const G (&rec)[FD_NR], int cmd_type, G (&x)[FD_NX], EnvState<E>& e)
 {
 #pragma unroll
     for (int k = 0; k < FD_NX; ++k) x[k] = G(0);
@@ -467,16 +475,16 @@ __device__ __forceinline__ void env_apply_reset(const G (&rec)[FD_NR], int cmd_t
     x[6] = rec[FD_R_ROLL]; x[7] = rec[FD_R_PITCH]; x[8] = rec[FD_R_YAW];
     x[9] = rec[FD_R_P]; x[10] = rec[FD_R_Q]; x[11] = rec[FD_R_R];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { e.cmd[k] = G(0); e.prev_err[k] = G(0); e.sign_changes[k] = G(0); e.prev_action[k] = G(0); }
+    for (int k = 0; k < 3; ++k) { e.cmd[k] = E(0); e.prev_err[k] = E(0); e.sign_changes[k] = E(0); e.prev_action[k] = E(0); }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) e.sched[k] = G(0);
-    e.prev_action[3] = G(0.5);                                                   // rate_env.py:193
+    for (int k = 0; k < 4; ++k) e.sched[k] = E(0);
+    e.prev_action[3] = E(0.5);                                                   // rate_env.py:193
     if (cmd_type == FD_CMD_STEP) {
-        e.cmd[0] = rec[FD_R_CMD0]; e.cmd[1] = rec[FD_R_CMD1]; e.cmd[2] = rec[FD_R_CMD2];
+        e.cmd[0] = E(rec[FD_R_CMD0]); e.cmd[1] = E(rec[FD_R_CMD1]); e.cmd[2] = E(rec[FD_R_CMD2]);
     } else if (cmd_type == FD_CMD_RAMP || cmd_type == FD_CMD_SINE) {
-        e.sched[0] = rec[FD_R_CMD0]; e.sched[1] = rec[FD_R_CMD1]; e.sched[2] = rec[FD_R_CMD2]; e.sched[3] = rec[FD_R_CMD3];
+        e.sched[0] = E(rec[FD_R_CMD0]); e.sched[1] = E(rec[FD_R_CMD1]); e.sched[2] = E(rec[FD_R_CMD2]); e.sched[3] = E(rec[FD_R_CMD3]);
     }
-    e.settle_timer = G(0); e.is_settled = G(0); e.time = G(0); e.ep_return = G(0);
+    e.settle_timer = E(0); e.is_settled = E(0); e.time = E(0); e.ep_return = E(0);
 }
 
 template <typename G>
@@ -490,6 +498,13 @@ __device__ __forceinline__ void load_env_consts(const double* __restrict__ EC, E
     const double r = EC[FD_EC_DT] / EC[FD_EC_DT_PHYSICS];                       // simulation_backend.py:95
     const long ns = long(r);
     ec.n_sub = ns < 1 ? 1 : int(ns);
+    // rewards.py:205-209: `timer += dt; if timer >= 0.2` in fp64 -- 0.02 x 10 accumulates to 0.19999999999999998, so the bonus
+    // starts at the 11th settled step.  The fp32 env words carry the step COUNT; this is the count the sum first reaches 0.2 at.
+    const double dts = EC[FD_EC_DT];
+    int k = 0;
+    if (dts >= 1.0e-3) { double t = 0.0; while (t < 0.2 && k < 256) { t += dts; ++k; } }
+    else k = int(0.2 / dts) + 1;
+    ec.settle_steps = k;
 }
 
 template <typename G>
@@ -524,9 +539,9 @@ __device__ __forceinline__ void store_obs_tile(float* tile /*[64*19]*/, const fl
     __builtin_amdgcn_wave_barrier();
 }
 
-template <typename S>
+template <typename S, typename E>
 __global__ void __launch_bounds__(FD_BLOCK)
-rate_env_reset_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict__ eis, float* __restrict__ pid_state,
+rate_env_reset_kernel(S* __restrict__ xs, E* __restrict__ es, int32_t* __restrict__ eis, float* __restrict__ pid_state,
                       const uint8_t* __restrict__ mask, const double* __restrict__ EC, const double* __restrict__ pool,
                       int pool_depth, uint64_t seed, float* __restrict__ obs_out, int64_t n)
 {
@@ -538,7 +553,7 @@ rate_env_reset_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restric
     EnvConsts<S> ec;
     load_env_consts<S>(EC, ec);
     S x[FD_NX];
-    EnvState<S> e;
+    EnvState<E> e;
     float o[FD_OBS_DIM];
 #pragma unroll
     for (int k = 0; k < FD_OBS_DIM; ++k) o[k] = 0.0f;
@@ -548,21 +563,21 @@ rate_env_reset_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restric
             const int32_t episode = eis[FD_EI_EPISODE * n + i];
             S rec[FD_NR];
             fetch_reset_record<S>(pool, pool_depth, seed, i, episode, ec, rec);
-            env_apply_reset<S>(rec, ec.cmd_type, x, e);
+            env_apply_reset<S, E>(rec, ec.cmd_type, x, e);
 #pragma unroll
             for (int k = 0; k < FD_NX; ++k) xs[k * n + i] = x[k];
-            env_store<S>(e, es, n, i);
+            env_store<E>(e, es, n, i);
             eis[FD_EI_STEP * n + i] = 0;
             eis[FD_EI_EPISODE * n + i] = episode + 1;
             if (pid_state) for (int k = 0; k < 3 * FD_NPS; ++k) pid_state[k * n + i] = 0.0f;
         } else {
 #pragma unroll
             for (int k = 0; k < FD_NX; ++k) x[k] = xs[k * n + i];
-            env_load<S>(e, es, n, i);
+            env_load<E>(e, es, n, i);
         }
         S airspeed, altitude;
         airspeed_altitude<S>(x, airspeed, altitude);
-        env_observation<S>(x, e, airspeed, altitude, o);
+        env_observation<S, S, E>(x, e, airspeed, altitude, o);
     }
     store_obs_tile(s_tile[wave], o, lane, obs_out, lm.wave_first, n);
 }
@@ -572,7 +587,7 @@ rate_env_reset_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restric
 // (1 Mi envs: 1.16e9 -> 1.56e9 env-steps/s).  The launcher picks by batch size; the arithmetic is the same.
 template <typename S, typename T, bool OCC2>
 __global__ void __launch_bounds__(FD_BLOCK, OCC2 ? 2 : 1)
-rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict__ eis,
+rate_env_step_kernel(S* __restrict__ xs, typename EnvOf<S, T>::type* __restrict__ es, int32_t* __restrict__ eis,
                      const uint8_t* __restrict__ type, const double* __restrict__ params, int n_types,
                      const double* __restrict__ EC,
                      const float* __restrict__ actions /*[n][4] or null => in-kernel rate PID*/,
@@ -603,15 +618,16 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
 
     // ---- every per-env global load is issued HERE, before the parameter staging and its barrier: the HBM round trip of
     // the state overlaps the staging chain instead of following it
+    using E = typename EnvOf<S, T>::type;
     S x[FD_NX];
-    EnvState<S> e;
+    EnvState<E> e;
     int32_t step = 0, episode = 0;
     int ty = 0;
     float4 av = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (active) {
 #pragma unroll
         for (int k = 0; k < FD_NX; ++k) x[k] = xs[k * n + i];
-        env_load<S>(e, es, n, i, uses_sched);
+        env_load<E>(e, es, n, i, uses_sched);
         step = eis[FD_EI_STEP * n + i];
         episode = eis[FD_EI_EPISODE * n + i];
         if (actions) av = reinterpret_cast<const float4*>(actions)[i];
@@ -652,7 +668,7 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
                 st[k] = PidState{ pid_state[(k * FD_NPS + 0) * n + i], pid_state[(k * FD_NPS + 1) * n + i], pid_state[(k * FD_NPS + 2) * n + i] };
             }
             const S pid_dt = s_consts[FD_C_PID_DT] > S(0) ? s_consts[FD_C_PID_DT] : ec.dt;
-            const Surfaces<S> sf = rate_agent<S>(cfg, st, s_consts, e.cmd[0], e.cmd[1], e.cmd[2], s_consts[FD_C_PID_THROTTLE], x, pid_dt);
+            const Surfaces<S> sf = rate_agent<S>(cfg, st, s_consts, S(e.cmd[0]), S(e.cmd[1]), S(e.cmd[2]), s_consts[FD_C_PID_THROTTLE], x, pid_dt);
             a_in[0] = float(sf.aileron); a_in[1] = float(sf.elevator); a_in[2] = float(sf.rudder); a_in[3] = float(sf.throttle);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -682,16 +698,17 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
         C.set(P, a[1], a[0], a[2], a[3]);                                         // action = [ail, elev, rud, thr]
         const S dt_sub = ec.dt / S(ec.n_sub);
         rk4_substeps<S, T>(P, Lm, C, x, dt_sub, ec.n_sub);
-        e.time += ec.dt;                                                          // :241-242
+        if constexpr (sizeof(E) == sizeof(S)) e.time += E(ec.dt);                 // :241-242 (the reference's accumulated sum)
+        else e.time = E(S(step + 1) * ec.dt);                                     // fp32 env words: exact product, not an fp32 running sum
         step += 1;
 
         // ---- _update_command (rate_env.py:342-372) ------------------------------------------------------------
         if (ec.cmd_type == FD_CMD_RAMP) {
-            const S t = e.time;
+            const S t = S(e.time);
             if (t < S(3)) {
                 const S alpha = t / S(3);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) e.cmd[k] = (S(1) - alpha) * S(0) + alpha * e.sched[k];
+                for (int k = 0; k < 3; ++k) e.cmd[k] = E((S(1) - alpha) * S(0) + alpha * S(e.sched[k]));
             } else {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) e.cmd[k] = e.sched[k];
@@ -711,11 +728,11 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
                 delta[0] = S(n0) * sd * ec.mr0; delta[1] = S(n1) * sd * ec.mr1; delta[2] = S(n2) * sd * ec.mr2;
             }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) e.cmd[k] = clipv(e.cmd[k] + delta[k], -ec.max_rate(k), ec.max_rate(k));
+            for (int k = 0; k < 3; ++k) e.cmd[k] = E(clipv(S(e.cmd[k]) + delta[k], -ec.max_rate(k), ec.max_rate(k)));
         } else if (ec.cmd_type == FD_CMD_SINE) {
-            const S sn = M<S>::sin(S(2.0 * FD_PI) * e.sched[3] * e.time);
+            const S sn = M<S>::sin(S(2.0 * FD_PI) * S(e.sched[3]) * S(e.time));
 #pragma unroll
-            for (int k = 0; k < 3; ++k) e.cmd[k] = e.sched[k] * sn;
+            for (int k = 0; k < 3; ++k) e.cmd[k] = E(S(e.sched[k]) * sn);
         }
 
         // ---- reward, termination (rate_env.py:247-294,437-460) -------------------------------------------------
@@ -726,17 +743,17 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
         const A airspeed = M<A>::sqrt(u_ * u_ + v_ * v_ + w_ * w_), altitude = -A(x[2]);      // simplified_6dof.py:295-331
         const A err[3] = { A(e.cmd[0]) - A(x[9]), A(e.cmd[1]) - A(x[10]), A(e.cmd[2]) - A(x[11]) };
         const A aa[4] = { A(a[0]), A(a[1]), A(a[2]), A(a[3]) };
-        A rew = env_reward<S, A>(e, err, aa, airspeed, altitude, roll_, pitch_, ec.dt);
+        A rew = env_reward<E, A>(e, err, aa, airspeed, altitude, roll_, pitch_, ec.dt, ec.settle_steps);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) e.prev_action[k] = a[k];                      // :282
+        for (int k = 0; k < 4; ++k) e.prev_action[k] = E(a[k]);                   // :282
         term = (altitude < A(5)) || (M<A>::abs(roll_) > deg2rad<A>(120.0)) || (M<A>::abs(pitch_) > deg2rad<A>(80.0)) ||
                (airspeed < A(8));
         const bool trunc = step >= ec.max_steps;
         if (term && !trunc) rew += A(-100);                                       // :289-292
         reward = S(rew) + res_bonus;
-        e.ep_return += reward;
+        e.ep_return += E(reward);
         done = term || trunc;
-        env_observation<S, A>(x, e, airspeed, altitude, o);
+        env_observation<S, A, E>(x, e, airspeed, altitude, o);
         if (reward_f32) reward_f32[i] = float(reward);
         if (reward_full) reward_full[i] = reward;
         terminated[i] = term ? 1 : 0;
@@ -767,17 +784,17 @@ rate_env_step_kernel(S* __restrict__ xs, S* __restrict__ es, int32_t* __restrict
         if (done && auto_reset) {
             S rec[FD_NR];
             fetch_reset_record<S>(pool, pool_depth, seed, i, episode, ec, rec);
-            env_apply_reset<S>(rec, ec.cmd_type, x, e);
+            env_apply_reset<S, E>(rec, ec.cmd_type, x, e);
             step = 0;
             episode += 1;
             S airspeed, altitude;
             airspeed_altitude<S>(x, airspeed, altitude);
-            env_observation<S>(x, e, airspeed, altitude, o);
+            env_observation<S, S, E>(x, e, airspeed, altitude, o);
             if (pid_mode) for (int k = 0; k < 3 * FD_NPS; ++k) pid_state[k * n + i] = 0.0f;   // pid_agent.reset()
         }
 #pragma unroll
         for (int k = 0; k < FD_NX; ++k) xs[k * n + i] = x[k];
-        env_store<S>(e, es, n, i, uses_sched);
+        env_store<E>(e, es, n, i, uses_sched);
         eis[FD_EI_STEP * n + i] = step;
         eis[FD_EI_EPISODE * n + i] = episode;
     }
@@ -924,18 +941,18 @@ FD_DEFINE_CASCADE(fdyn_cascade_step_f64, double, double)
 FD_DEFINE_CASCADE(fdyn_cascade_step_mixed, double, float)
 FD_DEFINE_CASCADE(fdyn_cascade_step_f32, float, float)
 
-#define FD_DEFINE_ENV(SUFFIX, S, T)                                                                          \
-    int fdyn_rate_env_reset_##SUFFIX(S* x, S* e, int32_t* ei, float* pid_state, const uint8_t* mask,         \
+#define FD_DEFINE_ENV(SUFFIX, S, E, T)                                                                       \
+    int fdyn_rate_env_reset_##SUFFIX(S* x, E* e, int32_t* ei, float* pid_state, const uint8_t* mask,         \
                                      const double* env_consts, const double* pool, int pool_depth,           \
                                      uint64_t seed, float* obs_out, int64_t n, void* stream)                 \
     {                                                                                                        \
         FD_CHECK_COMMON(n, 1)                                                                                \
         if (pool && pool_depth < 1) return FDYN_ERR_BAD_SIZE;                                                \
-        hipLaunchKernelGGL((rate_env_reset_kernel<S>), dim3(grid_for(n)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
+        hipLaunchKernelGGL((rate_env_reset_kernel<S, E>), dim3(grid_for(n)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
                            x, e, ei, pid_state, mask, env_consts, pool, pool_depth, seed, obs_out, n); \
         return launch_status();                                                                              \
     }                                                                                                        \
-    int fdyn_rate_env_step_##SUFFIX(S* x, S* e, int32_t* ei, const uint8_t* type, const double* params,      \
+    int fdyn_rate_env_step_##SUFFIX(S* x, E* e, int32_t* ei, const uint8_t* type, const double* params,      \
                                     int n_types, const double* env_consts, const float* actions,             \
                                     float* pid_state, const float* pid_cfg, const double* casc_consts,       \
                                     float* actions_out, const S* rw_delta, const double* pool, int pool_depth, \
@@ -966,8 +983,8 @@ FD_DEFINE_CASCADE(fdyn_cascade_step_f32, float, float)
                            ev_cap, n);                                                                  \
         return launch_status();                                                                              \
     }
-FD_DEFINE_ENV(f64, double, double)
-FD_DEFINE_ENV(mixed, double, float)
-FD_DEFINE_ENV(f32, float, float)
+FD_DEFINE_ENV(f64, double, double, double)
+FD_DEFINE_ENV(mixed, double, float, float)
+FD_DEFINE_ENV(f32, float, float, float)
 
 }  // extern "C"

@@ -43,7 +43,9 @@ class GpuRateVecEnv:
         self.n_types = self.params.shape[0]
         self.type_index = None if type_index is None else torch.as_tensor(np.asarray(type_index, np.uint8), device=dev)
         self.x = torch.zeros((L.FD_NX, n), dtype=self.dtype, device=dev)
-        self.e = torch.zeros((L.FD_NE, n), dtype=self.dtype, device=dev)
+        # env words: fp32 in the fp32-evaluation variants (272 of the 660 B per env-step as fp64 rows); FD_E_SETTLE_TIMER then
+        # counts settled steps and FD_E_TIME is step * dt (include/fdyn.h)
+        self.e = torch.zeros((L.FD_NE, n), dtype=torch.float64 if precision == "f64" else torch.float32, device=dev)
         self.ei = torch.zeros((L.FD_NEI, n), dtype=torch.int32, device=dev)
         self.obs = torch.zeros((n, L.FD_OBS_DIM), dtype=torch.float32, device=dev)
         self.rewards = torch.zeros(n, dtype=torch.float32, device=dev)

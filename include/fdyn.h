@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define FDYN_ABI_VERSION 1
+#define FDYN_ABI_VERSION 2          /* 2: sharded episode-end records (FD_EV_SHARDS), fp32 env words in the mixed variant */
 
 /* return codes: 0 ok; >0 a hipError_t from the launch; <0 argument errors */
 #define FDYN_OK 0
@@ -121,7 +121,8 @@ int fdyn_agent_step_f32(int level, float* x, float* pid_state, const uint8_t* ty
                         int n_steps, float* surf_out, void* stream);
 
 /* ---- rate-control env ------------------------------------------------------------------------------------------
- * x [FD_NX][n] ; e [FD_NE][n] (FD_E_*) ; ei [FD_NEI][n] int32 ; env_consts [FD_NEC] fp64 (FD_EC_*)
+ * x [FD_NX][n] ; e [FD_NE][n] (FD_E_*; fp64 in the f64 variant, fp32 in mixed and f32 -- there FD_E_SETTLE_TIMER counts settled
+ *   steps and FD_E_TIME is step * dt) ; ei [FD_NEI][n] int32 ; env_consts [FD_NEC] fp64 (FD_EC_*)
  * pool [n][pool_depth][FD_NR] fp64 host-presampled reset records (parity mode), or NULL = in-kernel Philox draws
  *      keyed by (seed, env, episode) (throughput mode)
  * reset: mask [n] uint8 (NULL = all) ; pid_state [3*FD_NPS][n] zeroed for reset envs if non-NULL ; obs_out [n][18]
@@ -137,11 +138,11 @@ int fdyn_agent_step_f32(int level, float* x, float* pid_state, const uint8_t* ty
  *        segments of ev_cap / FD_EV_SHARDS records (fdyn_layout.h); NULL = no records.
  *        ev_count_next [FD_EV_SHARDS] or NULL: a second counter set this launch clears, so two sets can be
  *        ping-ponged across steps without a memset on the stream                                              */
-#define FDYN_DECLARE_ENV(SUFFIX, S)                                                                             \
-    int fdyn_rate_env_reset_##SUFFIX(S* x, S* e, int32_t* ei, float* pid_state, const uint8_t* mask,            \
+#define FDYN_DECLARE_ENV(SUFFIX, S, E)                                                                          \
+    int fdyn_rate_env_reset_##SUFFIX(S* x, E* e, int32_t* ei, float* pid_state, const uint8_t* mask,            \
                                      const double* env_consts, const double* pool, int pool_depth,              \
                                      uint64_t seed, float* obs_out, int64_t n, void* stream);                   \
-    int fdyn_rate_env_step_##SUFFIX(S* x, S* e, int32_t* ei, const uint8_t* type, const double* params,         \
+    int fdyn_rate_env_step_##SUFFIX(S* x, E* e, int32_t* ei, const uint8_t* type, const double* params,         \
                                     int n_types, const double* env_consts, const float* actions,                \
                                     float* pid_state, const float* pid_cfg, const double* casc_consts,          \
                                     float* actions_out, const S* rw_delta, const double* pool, int pool_depth,  \
@@ -150,9 +151,9 @@ int fdyn_agent_step_f32(int level, float* x, float* pid_state, const uint8_t* ty
                                     S* reward_full, uint8_t* terminated, uint8_t* truncated,                    \
                                     int32_t* ev_count, int32_t* ev_count_next, int32_t* ev_int,                 \
                                     float* ev_flt, int ev_cap, int64_t n, void* stream);
-FDYN_DECLARE_ENV(f64, double)
-FDYN_DECLARE_ENV(mixed, double)
-FDYN_DECLARE_ENV(f32, float)
+FDYN_DECLARE_ENV(f64, double, double)
+FDYN_DECLARE_ENV(mixed, double, float)       /* fp32 env words: see fdyn_layout.h, FD_E_* */
+FDYN_DECLARE_ENV(f32, float, float)
 
 /* ---- policy-side fused kernels (csrc/policy_kernels.hip) ------------------------------------------------------------
  * LSTM cell point-wise update from pre-activation gates [B][4H] (PyTorch order i,f,g,o; bias already added by the

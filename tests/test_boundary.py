@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/fdyn.h but not exported"
     assert declared == set(_lib.SIGNATURES), "host binding table and header drifted apart"
-    assert lib.fdyn_abi_version() == 1
+    assert lib.fdyn_abi_version() == 2
 
 
 def test_code_object_is_gfx950():
