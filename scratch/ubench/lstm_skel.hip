@@ -24,6 +24,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#ifdef FD_ABL_SKELETON
+#define FD_MFMA(A, B, C) (C)
+#else
+#define FD_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
+#endif
 #include <stdlib.h>
 #include "../../include/fdyn.h"
 
@@ -49,14 +54,24 @@ __device__ __forceinline__ lds_ptr_t as_lds(void* p) { return reinterpret_cast<l
 // conservative (loads retire in order); the waits that order DMA against LDS reads are written by hand below.
 __device__ __forceinline__ void dma16(const void* g, void* l)
 {
+#ifdef FD_ABL_NOWEIGHTS
+    return;
+#endif
     const uint32_t lds_off = uint32_t(reinterpret_cast<uintptr_t>(l));      // low 32 bits of a generic LDS address = LDS offset
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_off), "v"(g) : "memory");      // m0 is reserved: the compiler never keeps a live value in it here
 }
 __device__ __forceinline__ float sigmoid_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanh_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
 // the same two functions of (acc + bias) with the bias folded into the exponent's FMA: sb = -bias * log2(e), tb = 2 bias log2(e)
+#ifdef FD_ABL_SKELETON
+__device__ __forceinline__ float sigmoid_b(float acc, float sb) { return acc + sb; }
+__device__ __forceinline__ float tanh_b(float acc, float tb) { return acc - tb; }
+#define FD_SKEL 1
+#else
+#define FD_SKEL 0
 __device__ __forceinline__ float sigmoid_b(float acc, float sb) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(acc, -1.4426950408889634f, sb))); }
 __device__ __forceinline__ float tanh_b(float acc, float tb) { return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(__builtin_fmaf(acc, 2.8853900817779268f, tb)) + 1.0f), 1.0f); }
+#endif
 __device__ __forceinline__ uint16_t f2bf(float f)
 {   // round-to-nearest-even, NaN stays NaN: one v_cvt_pk_bf16_f32 on gfx950 (the shift/add/select form costs six VALU ops)
     return __builtin_bit_cast(uint16_t, static_cast<__bf16>(f));
@@ -253,7 +268,7 @@ lstm_cell_mfma_dma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const
         const int lr = (e & 3) + 8 * (e >> 2) + 4 * hf;
         float c = ig[e];
         if (RECUR) c += sigmoid_b(accB0[e], pbf) * (s_keep[wave * 32 + lr] * cp[e]);
-        const float hv = sigmoid_b(accB1[e], pbo) * tanh_(c);
+        const float hv = FD_SKEL ? sigmoid_b(accB1[e], pbo) * c : sigmoid_b(accB1[e], pbo) * tanh_(c);
         const uint32_t off = uoff + pcol + uint32_t((e & 3) + 8 * (e >> 2)) * uH;
         if constexpr (FAST) {
             st_f32(c_base, off * 4u, c);
@@ -299,9 +314,9 @@ lstm_cell_mfma_dma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const
             for (int ks = 0; ks < KC_STEPS; ++ks) {
                 const bf16x8_t af = a[ch * KC_STEPS + ks];
                 const uint4 b0 = *reinterpret_cast<const uint4*>(wb + r * ROW + ks * 16 + hf * 8);
-                accA0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8_t, b0), accA0, 0, 0, 0);
+                accA0 = FD_MFMA(af, __builtin_bit_cast(bf16x8_t, b0), accA0);
                 const uint4 b1 = *reinterpret_cast<const uint4*>(wb + (NSLICE + r) * ROW + ks * 16 + hf * 8);
-                accA1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8_t, b1), accA1, 0, 0, 0);
+                accA1 = FD_MFMA(af, __builtin_bit_cast(bf16x8_t, b1), accA1);
             }
             if constexpr (PENDING) {
 #pragma unroll
@@ -340,10 +355,10 @@ lstm_cell_mfma_dma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const
                 const bf16x8_t af = a[ch * KC_STEPS + ks];
                 if (RECUR) {                                  // rows 0..31 of the chunk: gate f (zero-state layers have none)
                     const uint4 b0 = *reinterpret_cast<const uint4*>(wb + r * ROW + ks * 16 + hf * 8);
-                    accB0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8_t, b0), accB0, 0, 0, 0);
+                    accB0 = FD_MFMA(af, __builtin_bit_cast(bf16x8_t, b0), accB0);
                 }
                 const uint4 b1 = *reinterpret_cast<const uint4*>(wb + (NSLICE + r) * ROW + ks * 16 + hf * 8);   // o
-                accB1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8_t, b1), accB1, 0, 0, 0);
+                accB1 = FD_MFMA(af, __builtin_bit_cast(bf16x8_t, b1), accB1);
             }
             // C/D map of a 32x32 tile: col = lane & 31 (hidden unit), row = (e & 3) + 8 (e >> 2) + 4 hf
 #pragma unroll
