@@ -139,6 +139,7 @@ lstm_cell_mfma_dma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const
     static_assert(TOTAL_SLOTS % 64 == 0 && NG <= 7, "chunk must be a whole number of 64-slot groups");
     constexpr int BUF = CROWS * ROW;
     constexpr int EPC = 16 / NCHUNK;                      // epilogue elements folded into one chunk's MFMAs
+    constexpr int PD = 2;                                 // k-steps a B-operand LDS read runs ahead of its MFMAs
     __shared__ __attribute__((aligned(16))) uint16_t s_w[3 * BUF];
     __shared__ float s_keep[BM];
 
@@ -184,6 +185,12 @@ lstm_cell_mfma_dma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const
     FD_DMA_SEQ(0, 0)                                      // start the weight stream before the activation slab
     if (total_chunks > 1) { FD_DMA_SEQ(1, 1) }
 
+    if (RECUR) {                                          // episode-start mask -> LDS (before the slab loads: its wait must not cover them)
+        for (int i = tid; i < BM; i += THREADS) {
+            const int64_t b = int64_t(blockIdx.x) * BM + i;
+            s_keep[i] = (keep && b < B) ? keep[b] : 1.0f;
+        }
+    }
     // ---- A slab -> registers (masked h part).  Branch-free: rows past B read row B-1 (their results are never stored) and
     // the episode-start mask is a select, so all K/16 loads are in flight together (a guarded load per k-step makes
     // hipcc branch and drain vmcnt around each one).
@@ -206,13 +213,10 @@ lstm_cell_mfma_dma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const
             a[s] = __builtin_bit_cast(bf16x8_t, v);
         }
     }
-    if (RECUR) {
-        for (int i = tid; i < BM; i += THREADS) {
-            const int64_t b = int64_t(blockIdx.x) * BM + i;
-            s_keep[i] = (keep && b < B) ? keep[b] : 1.0f;
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // chunks 0 and 1 landed (and the slab is in registers)
+    // chunks 0 and 1 have landed once no more than the KSTEPS slab loads (all younger) are in flight: the slab itself keeps
+    // arriving under the first MFMAs (the compiler waits per fragment); a vmcnt(0) here held every wave until its whole 24 KB
+    // slab was in registers
+    wait_vmcnt(KSTEPS);
     __syncthreads();
 
     // Addresses of the epilogue: [per-wave base pointer] + [one 32-bit per-lane offset] + [compile-time row constant * H].
@@ -295,13 +299,25 @@ lstm_cell_mfma_dma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const
             FD_BLOCK_BEGIN(si, ch + 2)
             if (ch == 0 && PENDING && RECUR) wait_vmcnt(after_cp);          // the pending slice's c_prev has arrived
             const uint16_t* wb = s_w + cur * BUF;
+            // B operands are read PD k-steps ahead of the MFMAs that use them.  Left to the compiler every ds_read_b128 landed
+            // in the one register quad its MFMA then consumed -- read, s_waitcnt lgkmcnt(0), MFMA, read, wait, MFMA -- so each
+            // MFMA paid the full LDS latency (~100+ cycles with eight waves reading) on a 32-cycle instruction: the reason the
+            // matrix pipe sat at 26 % however the rest of the kernel was arranged.
+            uint4 pb0[PD + 1], pb1[PD + 1];
+#pragma unroll
+            for (int j = 0; j < PD; ++j) {
+                pb0[j] = *reinterpret_cast<const uint4*>(wb + r * ROW + j * 16 + hf * 8);
+                pb1[j] = *reinterpret_cast<const uint4*>(wb + (NSLICE + r) * ROW + j * 16 + hf * 8);
+            }
 #pragma unroll
             for (int ks = 0; ks < KC_STEPS; ++ks) {
                 const bf16x8_t af = a[ch * KC_STEPS + ks];
-                const uint4 b0 = *reinterpret_cast<const uint4*>(wb + r * ROW + ks * 16 + hf * 8);
-                accA0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8_t, b0), accA0, 0, 0, 0);
-                const uint4 b1 = *reinterpret_cast<const uint4*>(wb + (NSLICE + r) * ROW + ks * 16 + hf * 8);
-                accA1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8_t, b1), accA1, 0, 0, 0);
+                if (ks + PD < KC_STEPS) {
+                    pb0[(ks + PD) % (PD + 1)] = *reinterpret_cast<const uint4*>(wb + r * ROW + (ks + PD) * 16 + hf * 8);
+                    pb1[(ks + PD) % (PD + 1)] = *reinterpret_cast<const uint4*>(wb + (NSLICE + r) * ROW + (ks + PD) * 16 + hf * 8);
+                }
+                accA0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8_t, pb0[ks % (PD + 1)]), accA0, 0, 0, 0);
+                accA1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8_t, pb1[ks % (PD + 1)]), accA1, 0, 0, 0);
             }
             if constexpr (PENDING) {
 #pragma unroll
@@ -335,15 +351,22 @@ lstm_cell_mfma_dma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const
         for (int ch = 0; ch < NCHUNK; ++ch) {
             FD_BLOCK_BEGIN(si, NCHUNK + ch + 2)
             const uint16_t* wb = s_w + cur * BUF;
+            uint4 pb0[PD + 1], pb1[PD + 1];
+#pragma unroll
+            for (int j = 0; j < PD; ++j) {
+                if (RECUR) pb0[j] = *reinterpret_cast<const uint4*>(wb + r * ROW + j * 16 + hf * 8);
+                pb1[j] = *reinterpret_cast<const uint4*>(wb + (NSLICE + r) * ROW + j * 16 + hf * 8);
+            }
 #pragma unroll
             for (int ks = 0; ks < KC_STEPS; ++ks) {
                 const bf16x8_t af = a[ch * KC_STEPS + ks];
-                if (RECUR) {                                  // rows 0..31 of the chunk: gate f (zero-state layers have none)
-                    const uint4 b0 = *reinterpret_cast<const uint4*>(wb + r * ROW + ks * 16 + hf * 8);
-                    accB0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8_t, b0), accB0, 0, 0, 0);
+                if (ks + PD < KC_STEPS) {
+                    if (RECUR) pb0[(ks + PD) % (PD + 1)] = *reinterpret_cast<const uint4*>(wb + r * ROW + (ks + PD) * 16 + hf * 8);
+                    pb1[(ks + PD) % (PD + 1)] = *reinterpret_cast<const uint4*>(wb + (NSLICE + r) * ROW + (ks + PD) * 16 + hf * 8);
                 }
-                const uint4 b1 = *reinterpret_cast<const uint4*>(wb + (NSLICE + r) * ROW + ks * 16 + hf * 8);   // o
-                accB1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8_t, b1), accB1, 0, 0, 0);
+                if (RECUR)                                    // rows 0..31 of the chunk: gate f (zero-state layers have none)
+                    accB0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8_t, pb0[ks % (PD + 1)]), accB0, 0, 0, 0);
+                accB1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8_t, pb1[ks % (PD + 1)]), accB1, 0, 0, 0);   // o
             }
             // C/D map of a 32x32 tile: col = lane & 31 (hidden unit), row = (e & 3) + 8 (e >> 2) + 4 hf
 #pragma unroll
