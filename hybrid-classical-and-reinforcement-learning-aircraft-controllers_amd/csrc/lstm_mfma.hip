@@ -417,6 +417,9 @@ int launch(const void* x, const void* h_prev, const float* c_prev, const float* 
 
 }  // namespace
 
+extern "C" int fdyn_lstm_cell_mfma64_try(const void* x, int kx, const void* h_prev, int kh, const float* c_prev, const float* keep,
+                                         const void* W, const float* bias, void* h_out, float* c_out, int64_t B, int H, void* stream);   // lstm_mfma64.hip
+
 extern "C" int fdyn_lstm_cell_mfma(const void* x, int kx, const void* h_prev, int kh, const float* c_prev, const float* keep,
                                    const void* W, const float* bias, void* h_out, float* c_out, float* h_out_f32,
                                    int64_t B, int H, void* stream)
@@ -426,6 +429,12 @@ extern "C" int fdyn_lstm_cell_mfma(const void* x, int kx, const void* h_prev, in
     if (kh > 0 && (!h_prev || !c_prev)) return FDYN_ERR_NULL;
     if (B == 0) return FDYN_OK;
     hipStream_t st = (hipStream_t)stream;
+    // whole 256-row blocks of the (128, 256) cell, enough of them to give every CU one: the one-wave-per-SIMD kernel
+    static const bool use64 = [] { const char* e = getenv("FDYN_MFMA64"); return !(e && e[0] == '0'); }();
+    if (use64 && !h_out_f32 && B >= 128 * 256) {
+        const int rc = fdyn_lstm_cell_mfma64_try(x, kx, h_prev, kh, c_prev, keep, W, bias, h_out, c_out, B, H, stream);
+        if (rc) return rc > 0 ? FDYN_OK : int(hipGetLastError());
+    }
     if (kx == 128 && kh == 256) return launch<128, 256>(x, h_prev, c_prev, keep, W, bias, h_out, c_out, h_out_f32, B, H, st);
     if (kx == 128 && kh == 0) return launch<128, 0>(x, h_prev, c_prev, keep, W, bias, h_out, c_out, h_out_f32, B, H, st);
     if (kx == 256 && kh == 0) return launch<256, 0>(x, h_prev, c_prev, keep, W, bias, h_out, c_out, h_out_f32, B, H, st);
