@@ -55,15 +55,31 @@ __device__ __forceinline__ void dma16s(const void* base, uint32_t lane_byte_off,
 {
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(lds_off), "v"(lane_byte_off), "s"(base) : "memory");
 }
+// timing experiments only (FD64_ABL_PLAINLOAD / PLAINDSW): the same bytes by a plain load, and with an LDS write of a register quad
+__device__ __forceinline__ void abl_plain(const void* base, uint32_t off) { asm volatile("global_load_dwordx4 a[224:227], %0, %1" :: "v"(off), "s"(base) : "memory"); }
+template <int IMM> __device__ __forceinline__ void abl_plain_dsw(const void* base, uint32_t off, uint32_t laddr)
+{
+    asm volatile("global_load_dwordx4 a[224:227], %0, %1\n\tds_write_b128 %2, a[228:231] offset:%3" :: "v"(off), "s"(base), "v"(laddr), "n"(IMM) : "memory");
+}
+__device__ __forceinline__ void dma4s(const void* base, uint32_t lane_byte_off, uint32_t lds_off)      // timing experiment
+{
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" :: "s"(lds_off), "v"(lane_byte_off), "s"(base) : "memory");
+}
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N > 60 ? 60 : (N < 0 ? 0 : N)) : "memory"); }
 
 // acc += A(a[LO:LO+3]) x b ; the `zero` form starts a chain (C operand = inline constant 0)
 template <int LO> __device__ __forceinline__ void mfma_acc(f32x16_t& acc, const bf16x8_t& b)
 {
+#ifdef FD64_ABL_NOMFMA
+    asm volatile("" : "+v"(acc) : "v"(b)); return;
+#endif
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%2:%3], %1, %0" : "+v"(acc) : "v"(b), "n"(LO), "n"(LO + 3));
 }
 template <int LO> __device__ __forceinline__ void mfma_zero(f32x16_t& acc, const bf16x8_t& b)
 {
+#ifdef FD64_ABL_NOMFMA
+    asm volatile("" : "=&v"(acc) : "v"(b)); return;
+#endif
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%2:%3], %1, 0" : "=&v"(acc) : "v"(b), "n"(LO), "n"(LO + 3));
 }
 template <int LO, int IMM> __device__ __forceinline__ void ld_a4_s(const void* base, uint32_t voff)
@@ -76,6 +92,9 @@ template <int LO, int IMM> __device__ __forceinline__ void ld_a4_v(const void* v
 }
 template <int A, int IMM> __device__ __forceinline__ void ld_a1_s(const void* base, uint32_t voff)
 {
+#ifdef FD64_ABL_NOCP
+    return;
+#endif
     asm volatile("global_load_dword a[%2], %0, %1 offset:%3" :: "v"(voff), "s"(base), "n"(A), "n"(IMM) : "memory");
 }
 template <int A> __device__ __forceinline__ float rd_a()
@@ -105,12 +124,29 @@ lstm_cell_mfma64_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const u
     constexpr int BUF = 64 * ROW;                         // elements per chunk buffer
     constexpr int NSLICES = H / NSL;
     constexpr int PD = 2;                                 // k-steps a B fragment is requested ahead of its MFMAs
-    static_assert(KSTEPS % 3 == 0 && 96 * 2 == AG_CP && KSTEPS * 4 == 96, "register map is written for K = 384");
+#ifndef FD64_DMA_EVERY
+#define FD64_DMA_EVERY 3
+#endif
+    constexpr int DMA_EVERY = FD64_DMA_EVERY;             // one DMA instruction of the next chunk's request per this many MFMAs
+    // VMEM bookkeeping of a block (all compile-time).  In gap g = 12 sg + m the order is MFMA, DMA piece (if any), filler.
+    // P0 stores 4 + 4 words per super-group (m = 5, 10), P1 loads 4 words of c_prev per super-group (m = 0, 6, 9, 10).
+    constexpr int LAST_DMA_GAP = (NG - 1) * DMA_EVERY;
+    static_assert(LAST_DMA_GAP < 96, "the request must fit into the block");
+    constexpr auto p0_ops_from = [](int g) { int n = 0; for (int q = g; q < 96; ++q) n += (q % 12 == 5 || q % 12 == 10) ? 4 : 0; return n; };
+    constexpr auto p1_ops_from = [](int g) { int n = 0; for (int q = g; q < 96; ++q) n += (q % 12 == 0 || q % 12 == 6 || q % 12 == 9 || q % 12 == 10) ? 1 : 0; return n; };
+#if defined(FD64_DMA_STAGGER)
+    constexpr int LAST_DMA_LATEST = LAST_DMA_GAP + DMA_EVERY - 1;      // wave w's last piece follows MFMA LAST_DMA_GAP + w
+    static_assert(DMA_EVERY == 4 && LAST_DMA_LATEST < 96, "one gap per wave");
+#else
+    constexpr int LAST_DMA_LATEST = LAST_DMA_GAP;
+#endif
+    constexpr int P0_AFTER_DMA = p0_ops_from(LAST_DMA_LATEST);   // stores certainly younger than the block's last DMA piece
+    constexpr int P1_AFTER_DMA = p1_ops_from(LAST_DMA_LATEST);   // c_prev loads certainly younger than it
     __shared__ __attribute__((aligned(16))) uint16_t s_w[2 * BUF];
     __shared__ __attribute__((aligned(16))) float s_keep[BM64];
     __shared__ __attribute__((aligned(16))) float s_bias[4 * H];          // pre-scaled for the exponent FMAs
 
-    asm volatile("" ::: "a0", "a223");                    // the accumulator registers a[0:223] belong to the inline assembly below
+    asm volatile("" ::: "a0", "a223", "a231");                    // the accumulator registers a[0:223] belong to the inline assembly below
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int uwave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -131,6 +167,9 @@ lstm_cell_mfma64_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const u
     auto slice_of = [&](int i) { return (i + sl_start) % NSLICES; };
     const uint32_t lds_w = uint32_t(reinterpret_cast<uintptr_t>(&s_w[0]));
     auto request = [&](int sl, int pass, int buf) {       // chunk (slice sl, pass) -> LDS buffer buf
+#ifdef FD64_ABL_NODMA
+        if (sl >= 0) return;
+#endif
         const uint16_t* org = W + (int64_t(pass) * H + sl * NSL) * K;
 #pragma unroll
         for (int j = 0; j < NG; ++j) dma16s(org, soff[j], lds_w + uint32_t(buf * BUF * 2 + ((uwave + 4 * j) % NGROUPS) * 1024));
@@ -148,6 +187,20 @@ lstm_cell_mfma64_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const u
     }
     request(slice_of(0), 0, 0);
     request(slice_of(0), 1, 1);
+    // piece J of a chunk (one DMA instruction of this wave), for the requests that are dealt out between the MFMAs of a block
+    auto piece = [&](auto J, const uint16_t* org, int buf) {
+        constexpr int j = decltype(J)::value;
+#if defined(FD64_ABL_PLAINLOAD)
+        abl_plain(org, soff[j]);
+#elif defined(FD64_ABL_PLAINDSW)
+        abl_plain_dsw<j * 1024>(org, soff[j], uint32_t(lane * 16 + buf * BUF * 2));
+#elif defined(FD64_ABL_DMA4)
+        dma4s(org, soff[j], lds_w + uint32_t(buf * BUF * 2 + ((uwave + 4 * j) % NGROUPS) * 1024));
+#elif !defined(FD64_ABL_NODMA)
+        dma16s(org, soff[j], lds_w + uint32_t(buf * BUF * 2 + ((uwave + 4 * j) % NGROUPS) * 1024));
+#endif
+    };
+    auto origin = [&](int sl, int pass) { return W + (int64_t(pass) * H + sl * NSL) * K; };
     {
         const uint16_t* xa = x + urow0 * KX;              // wave-uniform bases, one lane offset for both tiles
         const uint16_t* xb = x + (urow0 + 32) * KX;
@@ -192,8 +245,12 @@ lstm_cell_mfma64_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const u
     };
 
     // All MFMAs of one unit from LDS buffer BUFI into acc[2][2]: eight super-groups of three k-steps = 12 MFMAs.  MFMA m of
-    // super-group sg is followed by filler(sg, m) and a fence.  SLABWAIT: the slab fragments are still arriving (first unit).
-    auto unit = [&](auto bufc, f32x16_t (&acc)[2][2], auto slabwait_c, auto&& filler) {
+    // super-group sg (gap g = 12 sg + m) is followed by dma(piece g / DMA_EVERY) when g is a multiple of DMA_EVERY (the next
+    // chunk's request, dealt out over the first 40 % of the block: thirteen DMA instructions back to back at the top of a block
+    // cost each wave ~200 cycles apiece -- all four waves of the CU push 1 KB pieces through the one address path at once --
+    // 22 of the kernel's 72 us), then by filler(sg, m), then by a scheduling fence.
+    // SLABWAIT: the slab fragments are still arriving (first unit).
+    auto unit = [&](auto bufc, f32x16_t (&acc)[2][2], auto slabwait_c, auto&& dma, auto&& filler) {
         constexpr int BUFI = decltype(bufc)::value;
         constexpr bool SLABWAIT = decltype(slabwait_c)::value;
         bf16x8_t p0[PD + 1], p1[PD + 1];
@@ -207,20 +264,25 @@ lstm_cell_mfma64_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const u
                 constexpr int ks = 3 * sg + kk;
                 if constexpr (SLABWAIT) wait_vm<2 * KSTEPS - 2 * ks - 2>();
                 const bf16x8_t b0 = p0[ks % (PD + 1)], b1 = p1[ks % (PD + 1)];
-                if constexpr (ks + PD < KSTEPS) p0[(ks + PD) % (PD + 1)] = bfrag(BUFI, 0, ks + PD);
-                if constexpr (ks == 0) mfma_zero<AG_SLAB + 4 * ks>(acc[0][0], b0); else mfma_acc<AG_SLAB + 4 * ks>(acc[0][0], b0);
-                filler(SG, std::integral_constant<int, 4 * kk + 0>{});
-                FENCE();
-                if constexpr (ks == 0) mfma_zero<AG_SLAB + 96 + 4 * ks>(acc[0][1], b0); else mfma_acc<AG_SLAB + 96 + 4 * ks>(acc[0][1], b0);
-                filler(SG, std::integral_constant<int, 4 * kk + 1>{});
-                FENCE();
-                if constexpr (ks + PD < KSTEPS) p1[(ks + PD) % (PD + 1)] = bfrag(BUFI, 1, ks + PD);
-                if constexpr (ks == 0) mfma_zero<AG_SLAB + 4 * ks>(acc[1][0], b1); else mfma_acc<AG_SLAB + 4 * ks>(acc[1][0], b1);
-                filler(SG, std::integral_constant<int, 4 * kk + 2>{});
-                FENCE();
-                if constexpr (ks == 0) mfma_zero<AG_SLAB + 96 + 4 * ks>(acc[1][1], b1); else mfma_acc<AG_SLAB + 96 + 4 * ks>(acc[1][1], b1);
-                filler(SG, std::integral_constant<int, 4 * kk + 3>{});
-                FENCE();
+                sfor<0, 4>([&](auto MM) {
+                    constexpr int mm = decltype(MM)::value;
+                    constexpr int m = 4 * kk + mm, g = 12 * sg + m;
+                    constexpr int alo = AG_SLAB + 96 * (mm & 1) + 4 * ks;
+                    if constexpr (mm == 0 && ks + PD < KSTEPS) p0[(ks + PD) % (PD + 1)] = bfrag(BUFI, 0, ks + PD);
+                    if constexpr (mm == 2 && ks + PD < KSTEPS) p1[(ks + PD) % (PD + 1)] = bfrag(BUFI, 1, ks + PD);
+#ifdef FD64_DMA_FIRST
+                    if constexpr (g % DMA_EVERY == 0 && g / DMA_EVERY < NG) dma(std::integral_constant<int, g / DMA_EVERY>{});
+#endif
+                    if constexpr (ks == 0) mfma_zero<alo>(acc[mm >> 1][mm & 1], mm < 2 ? b0 : b1);
+                    else mfma_acc<alo>(acc[mm >> 1][mm & 1], mm < 2 ? b0 : b1);
+#if defined(FD64_DMA_STAGGER)
+                    if constexpr (g / DMA_EVERY < NG) { if (uwave == g % DMA_EVERY) dma(std::integral_constant<int, g / DMA_EVERY>{}); }
+#elif !defined(FD64_DMA_FIRST)
+                    if constexpr (g % DMA_EVERY == 0 && g / DMA_EVERY < NG) dma(std::integral_constant<int, g / DMA_EVERY>{});
+#endif
+                    filler(SG, std::integral_constant<int, m>{});
+                    FENCE();
+                });
             });
         });
         asm volatile("s_nop 15\n\ts_nop 3");              // MFMA result -> VALU read distance (the compiler cannot see into the asm)
@@ -230,13 +292,26 @@ lstm_cell_mfma64_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const u
     // C/D map of a 32x32 tile: column = lane & 31 (hidden unit), row = (e & 3) + 8 (e >> 2) + 4 hf.
     //   c' = sigmoid(f) keep c + ig ; h' = sigmoid(o) tanh(c')
     struct FO { float kp[4], cp[4], a[4], b[4], c[4], t[4]; };
-    auto fo_stage = [&](FO& s, auto SG, auto M) {
+    auto fo_stage = [&](FO& s, auto waitcp_c, auto SG, auto M) {
         constexpr int sg = decltype(SG)::value, m = decltype(M)::value;
+        constexpr bool WAITCP = decltype(waitcp_c)::value;
         constexpr int t = sg >> 2, j = sg & 3;
         float* cb = c_out + (urow0 + 32 * t + 8 * j) * H;                 // wave-uniform
         uint16_t* hb = h_out + (urow0 + 32 * t + 8 * j) * H;
         const uint32_t lo = uoff + pcol;
         if constexpr (m == 0) {
+            {   // c_prev group sg has landed: younger than its last load (previous P1 block, gap (sg, 10)) are that block's later
+                // loads and DMA pieces and this block's DMA pieces and stores so far
+                constexpr int g10 = 12 * sg + 10;
+                constexpr int p1_dma_after = NG - (g10 / DMA_EVERY + 1 < NG ? g10 / DMA_EVERY + 1 : NG);          // pieces in gaps > g10
+#if defined(FD64_DMA_STAGGER)       // wave w's piece k follows MFMA DMA_EVERY k + w: count what EVERY wave has issued (w = DMA_EVERY - 1)
+                constexpr int gq = 12 * sg - (DMA_EVERY - 1);
+                constexpr int p0_dma_before = gq < 0 ? 0 : (gq / DMA_EVERY + 1 < NG ? gq / DMA_EVERY + 1 : NG);
+#else
+                constexpr int p0_dma_before = (12 * sg) / DMA_EVERY + 1 < NG ? (12 * sg) / DMA_EVERY + 1 : NG;        // pieces in gaps <= 12 sg
+#endif
+                if constexpr (WAITCP) wait_vm<4 * (7 - sg) + p1_dma_after + p0_dma_before + 8 * sg>();
+            }
             const float4 k4 = *reinterpret_cast<const float4*>(&s_keep[uwave * 64 + 32 * t + 8 * j + 4 * hf]);
             s.kp[0] = k4.x; s.kp[1] = k4.y; s.kp[2] = k4.z; s.kp[3] = k4.w;
             sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.cp[i] = rd_a<AG_CP + 16 * t + 4 * j + i>(); });
@@ -256,7 +331,11 @@ lstm_cell_mfma64_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const u
             sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.t[i] = ex2(s.t[i]); });
             sfor<0, 4>([&](auto I) {
                 constexpr int i = decltype(I)::value;
+#ifdef FD64_ABL_NOSTORE
+                { const float cv_ = s.c[i]; asm volatile("" :: "v"(cv_)); }
+#else
                 *reinterpret_cast<float*>(reinterpret_cast<char*>(cb) + (lo * 4u + uint32_t(i * H * 4))) = s.c[i];
+#endif
             });
         } else if constexpr (m == 6) {
             sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.t[i] = s.t[i] + 1.0f; });
@@ -272,7 +351,11 @@ lstm_cell_mfma64_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const u
         } else if constexpr (m == 10) {
             sfor<0, 4>([&](auto I) {
                 constexpr int i = decltype(I)::value;
+#ifdef FD64_ABL_NOSTORE
+                { const float hv_ = s.t[i]; asm volatile("" :: "v"(hv_)); }
+#else
                 *reinterpret_cast<__bf16*>(reinterpret_cast<char*>(hb) + (lo * 2u + uint32_t(i * H * 2))) = static_cast<__bf16>(s.t[i]);
+#endif
             });
         }
     };
@@ -316,25 +399,36 @@ lstm_cell_mfma64_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const u
         const int sl = slice_of(si);
         const uint32_t col = uint32_t(sl * NSL + r);
         // ================= P0: (i, g) of slice sl -> set A (LDS buffer 0), under it the (f, o) epilogue of the previous slice
+        // and the request of this slice's (f, o) chunk -> buffer 1 (free since the last barrier)
         if constexpr (PENDING) {
-            request(sl, 1, 1);                            // this slice's (f, o) chunk -> buffer 1 (free since the last barrier)
-            wait_vm<NG>();                                // the pending slice's c_prev is in a[AG_CP ..]
             FO st;
-            unit(C0{}, aA, std::false_type{}, [&](auto SG, auto M) { fo_stage(st, SG, M); });
-            wait_vm<64>();                                // the (f, o) chunk is in LDS (the 64 stores are younger)
+            const uint16_t* org = origin(sl, 1);
+#ifdef FD64_ABL_NOFILL
+            unit(C0{}, aA, std::false_type{}, [&](auto J) { piece(J, org, 1); }, [&](auto SG, auto M) { });
+            wait_vm<0>();
+#else
+            unit(C0{}, aA, std::false_type{}, [&](auto J) { piece(J, org, 1); }, [&](auto SG, auto M) { fo_stage(st, std::true_type{}, SG, M); });
+#ifdef FD64_ABL_NOSTORE
+            wait_vm<0>();
+#endif
+            wait_vm<P0_AFTER_DMA>();                      // the (f, o) chunk is in LDS (the stores after its last piece may stay in flight)
+#endif
         } else {
-            unit(C0{}, aA, std::true_type{}, [&](auto, auto) {});
+            unit(C0{}, aA, std::true_type{}, [&](auto) {}, [&](auto, auto) {});      // its (f, o) chunk was requested in the prologue
         }
         __syncthreads();
-        // ================= P1: (f, o) of slice sl -> set B (LDS buffer 1), under it the (i, g) epilogue of this slice
-        {
-            const int nsi = si + 1 < NSLICES ? si + 1 : si;
-            request(slice_of(nsi), 0, 0);                 // the next slice's (i, g) chunk -> buffer 0 (past the end: a harmless duplicate)
-        }
+        // ================= P1: (f, o) of slice sl -> set B (LDS buffer 1), under it the (i, g) epilogue of this slice and the
+        // request of the next slice's (i, g) chunk -> buffer 0 (past the end: a harmless duplicate)
+        const uint16_t* norg = origin(slice_of(si + 1 < NSLICES ? si + 1 : si), 0);
         const float bi = s_bias[col], bg = s_bias[2 * H + col];
         IG st;
-        unit(C1{}, aB, std::false_type{}, [&](auto SG, auto M) { ig_stage(st, bi, bg, col, SG, M); });
-        wait_vm<32>();                                    // the next (i, g) chunk is in LDS (the 32 c_prev loads are younger)
+#ifdef FD64_ABL_NOFILL
+        unit(C1{}, aB, std::false_type{}, [&](auto J) { piece(J, norg, 0); }, [&](auto SG, auto M) { });
+        wait_vm<0>();
+#else
+        unit(C1{}, aB, std::false_type{}, [&](auto J) { piece(J, norg, 0); }, [&](auto SG, auto M) { ig_stage(st, bi, bg, col, SG, M); });
+        wait_vm<P1_AFTER_DMA>();                          // the next (i, g) chunk is in LDS (the c_prev loads after its last piece are younger)
+#endif
         __syncthreads();
         pcol = col;
         pbo = s_bias[3 * H + col];
@@ -347,7 +441,7 @@ lstm_cell_mfma64_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const u
     wait_vm<0>();
     {
         FO st;
-        sfor<0, KSTEPS / 3>([&](auto SG) { sfor<0, 12>([&](auto M) { fo_stage(st, SG, M); }); });
+        sfor<0, KSTEPS / 3>([&](auto SG) { sfor<0, 12>([&](auto M) { fo_stage(st, std::false_type{}, SG, M); }); });
     }
 }
 
