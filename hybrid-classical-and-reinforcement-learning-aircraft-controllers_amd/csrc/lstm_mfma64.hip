@@ -11,7 +11,7 @@
 //   * a chunk is a whole unit (gate pair x 32 hidden units x all K = 384 columns, 49 KB padded): one barrier per 96 MFMAs
 //     instead of one per 24; two LDS buffers, chunk q + 1 requested by LDS-DMA at the top of chunk q's block;
 //   * the register file is split BY HAND: the slabs (192 registers), the cell state on its way in (32) live in accumulator
-//     registers a[0:223] that only inline assembly touches (MFMA A operands and load destinations may be AGPRs on gfx950);
+//     registers a[18:254] that only inline assembly touches (MFMA A operands and load destinations may be AGPRs on gfx950);
 //     the compiler owns the 256 architectural registers (two accumulator sets 128, sigmoid(i) tanh(g) 32, B fragments in
 //     flight 24, epilogue temporaries).  Left to the compiler (MFMA builtins) the accumulators went to AGPRs and every
 //     epilogue read became a copy, 53 registers spilled to scratch;
@@ -38,8 +38,13 @@ constexpr int NSL = 32;            // hidden units per slice
 constexpr int PAD = 8;             // bf16 elements (16 B) of LDS row padding
 
 // accumulator-register map (inline assembly only)
-constexpr int AG_SLAB = 0;         // a[96 t + 4 ks .. + 3]: slab fragment (row tile t, k-step ks)
-constexpr int AG_CP = 192;         // a[192 + 16 t + e]: c_prev of the slice whose (f, o) epilogue is pending
+// a[0 : AG_BASE - 1] are left to the compiler: when it runs out of architectural registers it parks values in the lowest
+// accumulator registers, and nothing can tell it that others are taken -- __graft_entry__.build() scans the ISA of this file
+// and refuses a build in which compiler-generated code touches a[AG_BASE] or above.
+constexpr int AG_BASE = 18;
+constexpr int AG_SLAB = AG_BASE;          // a[AG_SLAB + 96 t + 4 ks .. + 3]: slab fragment (row tile t, k-step ks)
+constexpr int AG_CP = AG_BASE + 192;      // a[AG_CP + 16 t + e]: c_prev of the slice whose (f, o) epilogue is pending
+constexpr int AG_SOFF = AG_BASE + 224;    // a[AG_SOFF + j]: lane byte offset of DMA piece j inside a weight chunk
 
 __device__ __attribute__((aligned(16))) uint32_t fdyn_zero_row[128];      // 512 zero bytes: the h row of an episode that just started
 
@@ -51,20 +56,14 @@ template <int I, int N, class F> __device__ __forceinline__ void sfor(F&& f)
 
 // 64 lanes x 16 bytes from global memory (scalar base + 32-bit lane byte offset) to 1 KB of LDS at byte offset `lds_off`
 // (wave-uniform).  Inline assembly for the reason given in lstm_mfma.hip: the compiler must not count it.
-__device__ __forceinline__ void dma16s(const void* base, uint32_t lane_byte_off, uint32_t lds_off)
+// the lane offset is kept in accumulator register a[A] (13 offsets are 13 architectural registers the epilogue needs)
+template <int A> __device__ __forceinline__ void dma16a(const void* base, uint32_t lds_off)
 {
-    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(lds_off), "v"(lane_byte_off), "s"(base) : "memory");
+    uint32_t t;
+    asm volatile("v_accvgpr_read_b32 %0, a[%3]\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
+                 : "=&v"(t) : "s"(lds_off), "s"(base), "n"(A) : "memory");
 }
-// timing experiments only (FD64_ABL_PLAINLOAD / PLAINDSW): the same bytes by a plain load, and with an LDS write of a register quad
-__device__ __forceinline__ void abl_plain(const void* base, uint32_t off) { asm volatile("global_load_dwordx4 a[224:227], %0, %1" :: "v"(off), "s"(base) : "memory"); }
-template <int IMM> __device__ __forceinline__ void abl_plain_dsw(const void* base, uint32_t off, uint32_t laddr)
-{
-    asm volatile("global_load_dwordx4 a[224:227], %0, %1\n\tds_write_b128 %2, a[228:231] offset:%3" :: "v"(off), "s"(base), "v"(laddr), "n"(IMM) : "memory");
-}
-__device__ __forceinline__ void dma4s(const void* base, uint32_t lane_byte_off, uint32_t lds_off)      // timing experiment
-{
-    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" :: "s"(lds_off), "v"(lane_byte_off), "s"(base) : "memory");
-}
+template <int A> __device__ __forceinline__ void wr_a(uint32_t v) { asm volatile("v_accvgpr_write_b32 a[%1], %0" :: "v"(v), "n"(A)); }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N > 60 ? 60 : (N < 0 ? 0 : N)) : "memory"); }
 
 // acc += A(a[LO:LO+3]) x b ; the `zero` form starts a chain (C operand = inline constant 0)
@@ -123,30 +122,23 @@ lstm_cell_mfma64_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const u
     constexpr int NG = (NGROUPS + 3) / 4;                 // DMA instructions per chunk per wave, the same for every wave
     constexpr int BUF = 64 * ROW;                         // elements per chunk buffer
     constexpr int NSLICES = H / NSL;
-    constexpr int PD = 2;                                 // k-steps a B fragment is requested ahead of its MFMAs
-#ifndef FD64_DMA_EVERY
-#define FD64_DMA_EVERY 3
-#endif
-    constexpr int DMA_EVERY = FD64_DMA_EVERY;             // one DMA instruction of the next chunk's request per this many MFMAs
+    constexpr int PD = 1;                                 // k-steps a B fragment is requested ahead of its MFMAs
+    constexpr int DMA_EVERY = 3;                          // one DMA instruction of the next chunk's request per this many MFMAs
     // VMEM bookkeeping of a block (all compile-time).  In gap g = 12 sg + m the order is MFMA, DMA piece (if any), filler.
     // P0 stores 4 + 4 words per super-group (m = 5, 10), P1 loads 4 words of c_prev per super-group (m = 0, 6, 9, 10).
     constexpr int LAST_DMA_GAP = (NG - 1) * DMA_EVERY;
     static_assert(LAST_DMA_GAP < 96, "the request must fit into the block");
     constexpr auto p0_ops_from = [](int g) { int n = 0; for (int q = g; q < 96; ++q) n += (q % 12 == 5 || q % 12 == 10) ? 4 : 0; return n; };
+    constexpr auto p0_stores_before_sg = [](int sg) { return 8 * sg; };
     constexpr auto p1_ops_from = [](int g) { int n = 0; for (int q = g; q < 96; ++q) n += (q % 12 == 0 || q % 12 == 6 || q % 12 == 9 || q % 12 == 10) ? 1 : 0; return n; };
-#if defined(FD64_DMA_STAGGER)
-    constexpr int LAST_DMA_LATEST = LAST_DMA_GAP + DMA_EVERY - 1;      // wave w's last piece follows MFMA LAST_DMA_GAP + w
-    static_assert(DMA_EVERY == 4 && LAST_DMA_LATEST < 96, "one gap per wave");
-#else
     constexpr int LAST_DMA_LATEST = LAST_DMA_GAP;
-#endif
     constexpr int P0_AFTER_DMA = p0_ops_from(LAST_DMA_LATEST);   // stores certainly younger than the block's last DMA piece
     constexpr int P1_AFTER_DMA = p1_ops_from(LAST_DMA_LATEST);   // c_prev loads certainly younger than it
     __shared__ __attribute__((aligned(16))) uint16_t s_w[2 * BUF];
     __shared__ __attribute__((aligned(16))) float s_keep[BM64];
     __shared__ __attribute__((aligned(16))) float s_bias[4 * H];          // pre-scaled for the exponent FMAs
 
-    asm volatile("" ::: "a0", "a223", "a231");                    // the accumulator registers a[0:223] belong to the inline assembly below
+    asm volatile("" ::: "a18", "a254");                    // the accumulator registers a[0:223] belong to the inline assembly below
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int uwave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -155,14 +147,13 @@ lstm_cell_mfma64_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const u
 
     // ---- weight stream.  Slot v of a chunk = padded row v / SPR, 16-byte column v % SPR (the pad column re-reads the last data
     // column); the 64 lanes of one DMA instruction fill slots 64 g .. 64 g + 63; wave w issues groups (w + 4 j) mod NGROUPS.
-    uint32_t soff[NG];
-#pragma unroll
-    for (int j = 0; j < NG; ++j) {
+    sfor<0, NG>([&](auto J) {
+        constexpr int j = decltype(J)::value;
         const int g = (uwave + 4 * j) % NGROUPS;
         const int v = g * 64 + lane;
         const int row = v / SPR, cs = v % SPR;
-        soff[j] = uint32_t((((row >> 5) * 2 * H + (row & 31)) * K + (cs < SPR - 1 ? cs : SPR - 2) * 8) * 2);
-    }
+        wr_a<AG_SOFF + j>(uint32_t((((row >> 5) * 2 * H + (row & 31)) * K + (cs < SPR - 1 ? cs : SPR - 2) * 8) * 2));
+    });
     const int sl_start = int((blockIdx.x + (blockIdx.x >> 3)) % unsigned(NSLICES));      // rotated slice order (see lstm_mfma.hip)
     auto slice_of = [&](int i) { return (i + sl_start) % NSLICES; };
     const uint32_t lds_w = uint32_t(reinterpret_cast<uintptr_t>(&s_w[0]));
@@ -171,8 +162,10 @@ lstm_cell_mfma64_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const u
         if (sl >= 0) return;
 #endif
         const uint16_t* org = W + (int64_t(pass) * H + sl * NSL) * K;
-#pragma unroll
-        for (int j = 0; j < NG; ++j) dma16s(org, soff[j], lds_w + uint32_t(buf * BUF * 2 + ((uwave + 4 * j) % NGROUPS) * 1024));
+        sfor<0, NG>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            dma16a<AG_SOFF + j>(org, lds_w + uint32_t(buf * BUF * 2 + ((uwave + 4 * j) % NGROUPS) * 1024));
+        });
     };
     // ---- prologue.  Every global load of this kernel is inline assembly with hand-counted waits: one load the compiler knows
     // about would bring its own s_waitcnt, computed without the DMA and slab loads in flight around it.
@@ -190,14 +183,8 @@ lstm_cell_mfma64_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const u
     // piece J of a chunk (one DMA instruction of this wave), for the requests that are dealt out between the MFMAs of a block
     auto piece = [&](auto J, const uint16_t* org, int buf) {
         constexpr int j = decltype(J)::value;
-#if defined(FD64_ABL_PLAINLOAD)
-        abl_plain(org, soff[j]);
-#elif defined(FD64_ABL_PLAINDSW)
-        abl_plain_dsw<j * 1024>(org, soff[j], uint32_t(lane * 16 + buf * BUF * 2));
-#elif defined(FD64_ABL_DMA4)
-        dma4s(org, soff[j], lds_w + uint32_t(buf * BUF * 2 + ((uwave + 4 * j) % NGROUPS) * 1024));
-#elif !defined(FD64_ABL_NODMA)
-        dma16s(org, soff[j], lds_w + uint32_t(buf * BUF * 2 + ((uwave + 4 * j) % NGROUPS) * 1024));
+#if !defined(FD64_ABL_NODMA)
+        dma16a<AG_SOFF + j>(org, lds_w + uint32_t(buf * BUF * 2 + ((uwave + 4 * j) % NGROUPS) * 1024));
 #endif
     };
     auto origin = [&](int sl, int pass) { return W + (int64_t(pass) * H + sl * NSL) * K; };
@@ -270,16 +257,9 @@ lstm_cell_mfma64_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const u
                     constexpr int alo = AG_SLAB + 96 * (mm & 1) + 4 * ks;
                     if constexpr (mm == 0 && ks + PD < KSTEPS) p0[(ks + PD) % (PD + 1)] = bfrag(BUFI, 0, ks + PD);
                     if constexpr (mm == 2 && ks + PD < KSTEPS) p1[(ks + PD) % (PD + 1)] = bfrag(BUFI, 1, ks + PD);
-#ifdef FD64_DMA_FIRST
-                    if constexpr (g % DMA_EVERY == 0 && g / DMA_EVERY < NG) dma(std::integral_constant<int, g / DMA_EVERY>{});
-#endif
                     if constexpr (ks == 0) mfma_zero<alo>(acc[mm >> 1][mm & 1], mm < 2 ? b0 : b1);
                     else mfma_acc<alo>(acc[mm >> 1][mm & 1], mm < 2 ? b0 : b1);
-#if defined(FD64_DMA_STAGGER)
-                    if constexpr (g / DMA_EVERY < NG) { if (uwave == g % DMA_EVERY) dma(std::integral_constant<int, g / DMA_EVERY>{}); }
-#elif !defined(FD64_DMA_FIRST)
                     if constexpr (g % DMA_EVERY == 0 && g / DMA_EVERY < NG) dma(std::integral_constant<int, g / DMA_EVERY>{});
-#endif
                     filler(SG, std::integral_constant<int, m>{});
                     FENCE();
                 });
@@ -291,6 +271,9 @@ lstm_cell_mfma64_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const u
     // ---- the (f, o) epilogue of the pending slice, elements (tile t, rows 8 j .. 8 j + 3 (+ 4 hf)), one stage per MFMA gap.
     // C/D map of a 32x32 tile: column = lane & 31 (hidden unit), row = (e & 3) + 8 (e >> 2) + 4 hf.
     //   c' = sigmoid(f) keep c + ig ; h' = sigmoid(o) tanh(c')
+    // (Tried: the 8 x 32 output tiles transposed through a per-wave LDS buffer and stored as ONE dwordx4 / dwordx2 instruction per
+    // group instead of 4 + 4 word stores -- 16 instead of 64 store instructions per slice, the same lines: 70.5 us against 70.3.
+    // What the stores cost is their lines, not their number.)
     struct FO { float kp[4], cp[4], a[4], b[4], c[4], t[4]; };
     auto fo_stage = [&](FO& s, auto waitcp_c, auto SG, auto M) {
         constexpr int sg = decltype(SG)::value, m = decltype(M)::value;
@@ -304,13 +287,8 @@ lstm_cell_mfma64_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const u
                 // loads and DMA pieces and this block's DMA pieces and stores so far
                 constexpr int g10 = 12 * sg + 10;
                 constexpr int p1_dma_after = NG - (g10 / DMA_EVERY + 1 < NG ? g10 / DMA_EVERY + 1 : NG);          // pieces in gaps > g10
-#if defined(FD64_DMA_STAGGER)       // wave w's piece k follows MFMA DMA_EVERY k + w: count what EVERY wave has issued (w = DMA_EVERY - 1)
-                constexpr int gq = 12 * sg - (DMA_EVERY - 1);
-                constexpr int p0_dma_before = gq < 0 ? 0 : (gq / DMA_EVERY + 1 < NG ? gq / DMA_EVERY + 1 : NG);
-#else
                 constexpr int p0_dma_before = (12 * sg) / DMA_EVERY + 1 < NG ? (12 * sg) / DMA_EVERY + 1 : NG;        // pieces in gaps <= 12 sg
-#endif
-                if constexpr (WAITCP) wait_vm<4 * (7 - sg) + p1_dma_after + p0_dma_before + 8 * sg>();
+                if constexpr (WAITCP) wait_vm<4 * (7 - sg) + p1_dma_after + p0_dma_before + p0_stores_before_sg(sg)>();
             }
             const float4 k4 = *reinterpret_cast<const float4*>(&s_keep[uwave * 64 + 32 * t + 8 * j + 4 * hf]);
             s.kp[0] = k4.x; s.kp[1] = k4.y; s.kp[2] = k4.z; s.kp[3] = k4.w;
@@ -331,7 +309,7 @@ lstm_cell_mfma64_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const u
             sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.t[i] = ex2(s.t[i]); });
             sfor<0, 4>([&](auto I) {
                 constexpr int i = decltype(I)::value;
-#ifdef FD64_ABL_NOSTORE
+#if defined(FD64_ABL_NOSTORE)
                 { const float cv_ = s.c[i]; asm volatile("" :: "v"(cv_)); }
 #else
                 *reinterpret_cast<float*>(reinterpret_cast<char*>(cb) + (lo * 4u + uint32_t(i * H * 4))) = s.c[i];
@@ -351,7 +329,7 @@ lstm_cell_mfma64_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const u
         } else if constexpr (m == 10) {
             sfor<0, 4>([&](auto I) {
                 constexpr int i = decltype(I)::value;
-#ifdef FD64_ABL_NOSTORE
+#if defined(FD64_ABL_NOSTORE)
                 { const float hv_ = s.t[i]; asm volatile("" :: "v"(hv_)); }
 #else
                 *reinterpret_cast<__bf16*>(reinterpret_cast<char*>(hb) + (lo * 2u + uint32_t(i * H * 2))) = static_cast<__bf16>(s.t[i]);

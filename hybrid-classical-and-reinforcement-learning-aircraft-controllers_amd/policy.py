@@ -66,6 +66,42 @@ def _run_seq(seq, x):
     return x
 
 
+# k order inside every block of 16 of a layer whose input arrives as the previous layer's MFMA output tile (csrc/policy_fe64.hip)
+_KPERM16 = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)
+
+
+def pack_fe_weights(w_emb, w1, w2, w_proj):
+    """The features extractor's four weight matrices as the byte image csrc/policy_fe64.hip streams through LDS.
+
+    Chunks in the order the kernel uses them -- embedding [128 rows, K 18 -> 32]; per 32-unit slice of LSTM layer 1 and 2 the
+    rows of gates (i, g) [64 rows] then of gate o [32 rows] (gate f multiplies the zero cell state and is not needed); per
+    32-feature slice of the projection [32 rows] -- each row K bf16 followed by 16 bytes of padding, each chunk padded to a
+    multiple of 1 KB.  Layers 1, 2 and the projection read their input straight out of the previous layer's MFMA output
+    registers, which fixes the order of k inside every block of 16 (_KPERM16)."""
+    bf = torch.bfloat16
+    H = w1.shape[0] // 4
+
+    def perm(K):
+        return torch.tensor([16 * (k // 16) + _KPERM16[k % 16] for k in range(K)], device=w1.device)
+
+    def chunk(rows):                      # rows [R, K] -> bytes of the padded LDS image, a whole number of 1 KB pieces
+        R = rows.shape[0]
+        img = torch.cat([rows.to(bf), torch.zeros(R, 8, dtype=bf, device=rows.device)], 1).reshape(-1)
+        pad = (-img.numel()) % 512
+        return torch.cat([img, torch.zeros(pad, dtype=bf, device=rows.device)])
+
+    parts = [chunk(F.pad(w_emb.detach().float(), (0, 32 - w_emb.shape[1])))]
+    for w in (w1, w2):
+        wp = w.detach().float()[:, perm(w.shape[1])]
+        for s in range(H // 32):
+            parts.append(chunk(torch.cat([wp[32 * s:32 * s + 32], wp[2 * H + 32 * s:2 * H + 32 * s + 32]], 0)))
+            parts.append(chunk(wp[3 * H + 32 * s:3 * H + 32 * s + 32]))
+    wq = w_proj.detach().float()[:, perm(w_proj.shape[1])]
+    for s in range(w_proj.shape[0] // 32):
+        parts.append(chunk(wq[32 * s:32 * s + 32]))
+    return torch.cat(parts).contiguous()
+
+
 class LSTMFeaturesExtractor(nn.Module):
     def __init__(self, obs_dim: int = OBS_DIM, features_dim: int = 128, lstm_hidden_size: int = 256, n_lstm_layers: int = 2):
         super().__init__()
@@ -168,6 +204,15 @@ class RateLSTMPolicy(nn.Module):
             "emb": lin(fe.embedding), "proj": lin(fe.output_proj), "pi": lin(self.pi_net), "vf": lin(self.vf_net),
             "act": lin([self.action_net])[0], "val": lin([self.value_net])[0],
         }
+        # the whole features extractor as one kernel (csrc/policy_fe64.hip) when it has the reference's shape
+        emb_l = [m for m in fe.embedding if isinstance(m, nn.Linear)]
+        proj_l = [m for m in fe.output_proj if isinstance(m, nn.Linear)]
+        if (fe.lstm.num_layers == 2 and len(emb_l) == 1 and len(proj_l) == 1 and emb_l[0].weight.shape == (128, OBS_DIM)
+                and fe.lstm.weight_ih_l0.shape == (1024, 128) and fe.lstm.weight_ih_l1.shape == (1024, 256)
+                and proj_l[0].weight.shape == (128, 256)):
+            new["fe_img"] = pack_fe_weights(emb_l[0].weight, fe.lstm.weight_ih_l0, fe.lstm.weight_ih_l1, proj_l[0].weight)
+            new["fe_bias"] = torch.cat([emb_l[0].bias.detach().float(), bias(fe.lstm, 0), bias(fe.lstm, 1),
+                                        proj_l[0].bias.detach().float()]).contiguous()
         old = getattr(self, "_inf", None)
         if old is None:
             self._inf = new
@@ -202,14 +247,23 @@ class RateLSTMPolicy(nn.Module):
         def shapes_ok(x_, w_, b_, kh_):      # the kernel trusts its sizes: check them on the host before every launch
             return (x_.is_contiguous() and x_.dtype == bf and x_.shape == (B, w_.shape[1] - kh_) and w_.is_contiguous()
                     and w_.dtype == bf and b_.dtype == torch.float32 and b_.numel() == w_.shape[0] and w_.shape[0] % 128 == 0)
-        x = self._mlp_bf16(obs.to(bf), inf["emb"])
-        for w, b in zip(inf["fe_w"], inf["fe_b"]):                       # zero-state layers: no h/c input at all
-            assert shapes_ok(x, w, b, 0), "lstm_cell_mfma operand shapes"
-            h = torch.empty((B, w.shape[0] // 4), dtype=bf, device=dev)
-            _lib.check(lib.fdyn_lstm_cell_mfma(x.data_ptr(), x.shape[1], None, 0, None, None, w.data_ptr(), b.data_ptr(),
-                                               h.data_ptr(), None, None, B, w.shape[0] // 4, st), "lstm_cell_mfma")
-            x = h
-        feats = self._mlp_bf16(x, inf["proj"])
+        if "fe_img" in inf and B % 256 == 0 and B >= 128 * 256 and not os.environ.get("FDYN_NO_FE64"):
+            # one kernel from the observation to the features: activations stay in registers between the four layers
+            o32 = obs.float().contiguous()
+            assert o32.shape == (B, OBS_DIM) and inf["fe_img"].numel() * 2 == lib.fdyn_policy_features_image_bytes() \
+                and inf["fe_bias"].numel() == 128 + 1024 + 1024 + 128, "policy_features operand shapes"
+            feats = torch.empty((B, 128), dtype=bf, device=dev)
+            _lib.check(lib.fdyn_policy_features(o32.data_ptr(), inf["fe_img"].data_ptr(), inf["fe_bias"].data_ptr(),
+                                                feats.data_ptr(), B, st), "policy_features")
+        else:
+            x = self._mlp_bf16(obs.to(bf), inf["emb"])
+            for w, b in zip(inf["fe_w"], inf["fe_b"]):                   # zero-state layers: no h/c input at all
+                assert shapes_ok(x, w, b, 0), "lstm_cell_mfma operand shapes"
+                h = torch.empty((B, w.shape[0] // 4), dtype=bf, device=dev)
+                _lib.check(lib.fdyn_lstm_cell_mfma(x.data_ptr(), x.shape[1], None, 0, None, None, w.data_ptr(), b.data_ptr(),
+                                                   h.data_ptr(), None, None, B, w.shape[0] // 4, st), "lstm_cell_mfma")
+                x = h
+            feats = self._mlp_bf16(x, inf["proj"])
         out = []
         outs = (None, None, None, None) if out_states is None else tuple(out_states)
         for (w, b, hp, cp), (ho, co) in zip(((inf["pi_w"], inf["pi_b"], states.pi_h, states.pi_c),

@@ -34,7 +34,7 @@
  *   fdyn_sensor_update_*   NoisySensorInterface.update       interfaces/sensor.py:199-243
  *   fdyn_sensor_observe    the same noise model on RateControlEnv observations (rate_env.py:374-408 layout)
  * Policy side (the reference delegates these to torch.nn.LSTM / SB3's PPO, which are not in its tree):
- *   fdyn_lstm_cell_mfma, fdyn_policy_heads, fdyn_gaussian_head   rollout: LSTM cell / output heads of
+ *   fdyn_policy_features, fdyn_lstm_cell_mfma, fdyn_policy_heads, fdyn_gaussian_head   rollout: LSTM cell / output heads of
  *                          learned_controllers/networks/lstm_policy.py:13-136 (+ sb3_contrib's actor / critic LSTMs)
  *   fdyn_lstm_cell_fwd/_bwd, fdyn_lstm_seq_fwd/_bwd              BPTT point-wise cell update and its gradient
  *   fdyn_gae, fdyn_ppo_loss, fdyn_colsum                         GAE(lambda), clipped-surrogate loss + gradient, bias gradients
@@ -207,6 +207,13 @@ int fdyn_ppo_loss(const float* mean, const float* actions, const float* log_std,
 int fdyn_lstm_cell_mfma(const void* x, int kx, const void* h_prev, int kh, const float* c_prev, const float* keep,
                         const void* W, const float* bias, void* h_out, float* c_out, float* h_out_f32,
                         int64_t B, int H, void* stream);
+/* The policy's features extractor as ONE kernel (csrc/policy_fe64.hip; learned_controllers/networks/lstm_policy.py:13-97):
+ * obs [B][18] fp32 -> Linear(18,128)+ReLU -> two zero-state LSTM layers (128->256->256) -> Linear(256,128)+ReLU -> feats
+ * [B][128] bf16, activations in registers between the layers.  weight_image: the four weight matrices as bf16 in the
+ * kernel's streaming order and LDS layout (fdyn_policy_features_image_bytes() bytes; host packer: policy.pack_fe_weights),
+ * bias [128 + 1024 + 1024 + 128] fp32 = embedding, b_ih + b_hh of layer 1 and 2, projection.  B % 256 == 0.               */
+int fdyn_policy_features_image_bytes(void);
+int fdyn_policy_features(const float* obs, const void* weight_image, const float* bias, void* feats, int64_t B, void* stream);
 /* Diagonal-Gaussian policy head: actions [B][4] = mean + exp(log_std) * N(0,1) (Philox keyed by seed, env, *step -- a
  * uint32 counter in DEVICE memory the caller increments on the stream, so graph replays draw fresh noise; or the mean
  * itself when deterministic), logp [B] = log-probability of the sampled action.  mean [B][4] bf16 (mean_bf16=1) or fp32. */

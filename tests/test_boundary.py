@@ -206,3 +206,35 @@ seed: 42
     assert b["imitation"] == {"n_episodes": 500, "difficulty": "easy", "save_path": "x.pkl", "epochs": 20, "batch_size": 256,
                               "learning_rate": 0.001}
     assert PPOConfig.from_dict(b["ppo"]).n_steps == 2048
+
+
+def test_fe_weight_image_layout():
+    """policy.pack_fe_weights lays the features extractor's weights out as csrc/policy_fe64.hip streams them: chunk order, row
+    padding, 1 KB chunk granularity and the k order inside blocks of 16 (replayed here from the kernel's constants)."""
+    import torch
+    from hcrl_amd.policy import pack_fe_weights, _KPERM16
+    torch.manual_seed(0)
+    bf = torch.bfloat16
+    w_emb, w1, w2, wp = (torch.randn(128, 18).to(bf).float(), torch.randn(1024, 128).to(bf).float(),
+                         torch.randn(1024, 256).to(bf).float(), torch.randn(128, 256).to(bf).float())
+    img = pack_fe_weights(w_emb, w1, w2, wp).float()
+    rowb = lambda K: 2 * K + 16                       # noqa: E731
+    pieces = lambda rows, K: (rows * rowb(K) + 1023) // 1024      # noqa: E731
+    off_a = pieces(128, 32)
+    off_b = off_a + 8 * (pieces(64, 128) + pieces(32, 128))
+    off_c = off_b + 8 * (pieces(64, 256) + pieces(32, 256))
+    assert img.numel() * 2 == (off_c + 4 * pieces(32, 256)) * 1024 == 702464
+
+    def at(piece_off, K, row, k):                     # element (row, k-slot) of the chunk that starts at `piece_off`
+        return img[piece_off * 512 + row * (K + 8) + k].item()
+    assert at(0, 32, 5, 7) == w_emb[5, 7].item() and at(0, 32, 5, 20) == 0.0
+    s = 3                                             # layer 1, slice 3: (i, g) chunk then o chunk
+    o1 = off_a + s * (pieces(64, 128) + pieces(32, 128))
+    for slot in (0, 5, 9, 127):
+        k = 16 * (slot // 16) + _KPERM16[slot % 16]
+        assert at(o1, 128, 2, slot) == w1[32 * s + 2, k].item()                     # gate i
+        assert at(o1, 128, 32 + 2, slot) == w1[512 + 32 * s + 2, k].item()          # gate g
+        assert at(o1 + pieces(64, 128), 128, 2, slot) == w1[768 + 32 * s + 2, k].item()   # gate o
+    o2 = off_b + 7 * (pieces(64, 256) + pieces(32, 256))
+    assert at(o2, 256, 40, 200) == w2[512 + 224 + 8, 16 * 12 + _KPERM16[8]].item()
+    assert at(off_c + 2 * pieces(32, 256), 256, 31, 37) == wp[64 + 31, 32 + _KPERM16[5]].item()

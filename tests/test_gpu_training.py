@@ -575,3 +575,52 @@ def test_episode_statistics_of_training_rollouts():
         assert count == len(rets) and count >= 64
         assert mean_ret == pytest.approx(np.mean(rets), rel=1e-9) and mean_len == pytest.approx(np.mean(lens))
         assert max(lens) <= 20                                       # truncation at episode_length / dt steps
+
+
+@pytest.mark.parametrize("B", [32768, 65536])
+def test_policy_features_kernel_matches_plain_torch_fp32(B):
+    """csrc/policy_fe64.hip (observation -> features in one kernel, activations in registers between the four layers) against
+    plain PyTorch fp32 on the same bf16-rounded weights with the SAME rounding points (every layer's output rounded to bf16),
+    and against the layer-wise device path it replaces.  Random weights with non-zero biases and an asymmetric observation
+    batch: a wrong k permutation, fragment order or gate offset cannot pass."""
+    from hcrl_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(11)
+    p = RateLSTMPolicy(compute_dtype=torch.bfloat16).cuda()
+    fe = p.features_extractor
+    with torch.no_grad():
+        for prm in fe.parameters():
+            prm.copy_(torch.randn_like(prm) * (0.5 if prm.dim() == 1 else 1.6 / prm.shape[-1] ** 0.5))
+    p.prepare_inference()
+    inf = p._inf
+    obs = torch.randn(B, 18, device="cuda") * torch.linspace(0.2, 2.0, 18, device="cuda")
+    feats = torch.empty((B, 128), dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.fdyn_policy_features(obs.data_ptr(), inf["fe_img"].data_ptr(), inf["fe_bias"].data_ptr(), feats.data_ptr(), B,
+                                        _lib.current_stream()), "policy_features")
+    torch.cuda.synchronize()
+    bf = lambda t: t.to(torch.bfloat16).float()      # noqa: E731
+    x = bf(torch.relu(bf(obs) @ bf(fe.embedding[0].weight).t() + fe.embedding[0].bias))
+    for k in range(2):
+        w = bf(getattr(fe.lstm, f"weight_ih_l{k}")); b = getattr(fe.lstm, f"bias_ih_l{k}") + getattr(fe.lstm, f"bias_hh_l{k}")
+        i, _, g, o = (x @ w.t() + b).chunk(4, 1)
+        x = bf(torch.sigmoid(o) * torch.tanh(torch.sigmoid(i) * torch.tanh(g)))
+    ref = torch.relu(x @ bf(fe.output_proj[0].weight).t() + fe.output_proj[0].bias)
+    err = (feats.float() - ref).abs().max().item()
+    assert err < 3e-2 * max(1.0, ref.abs().max().item()), err
+    assert (feats.float() - ref).abs().mean().item() < 2e-3
+    # the layer-wise path (hipBLASLt GEMMs + one MFMA cell kernel per layer)
+    os.environ["FDYN_NO_FE64"] = "1"
+    try:
+        st = p.initial_state(B, "cuda")
+        keep = torch.ones(B, device="cuda")
+        with torch.no_grad():
+            x2 = p._mlp_bf16(obs.to(torch.bfloat16), inf["emb"])
+            for w, b in zip(inf["fe_w"], inf["fe_b"]):
+                h = torch.empty((B, 256), dtype=torch.bfloat16, device="cuda")
+                _lib.check(lib.fdyn_lstm_cell_mfma(x2.data_ptr(), x2.shape[1], None, 0, None, None, w.data_ptr(), b.data_ptr(),
+                                                   h.data_ptr(), None, None, B, 256, _lib.current_stream()), "cell")
+                x2 = h
+            layerwise = p._mlp_bf16(x2, inf["proj"])
+    finally:
+        del os.environ["FDYN_NO_FE64"]
+    assert (feats.float() - layerwise.float()).abs().max().item() < 3e-2 * max(1.0, ref.abs().max().item())
