@@ -36,6 +36,10 @@ SIGNATURES = {
     "fdyn_lstm_cell_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i64, _i, _p]),
     "fdyn_lstm_seq_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _i, _p]),
     "fdyn_lstm_seq_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _i64, _i, _p]),
+    "fdyn_lstm_seq_bwd_bsum": (_i, [_p, _i, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i, _p]),
+    "fdyn_lstm_cell0_fwd": (_i, [_p, _i, _p, _p, _i64, _i, _p]),
+    "fdyn_lstm_cell0_bwd": (_i, [_p, _i, _p, _p, _p, _i64, _i64, _i, _p]),
+    "fdyn_colsum_partials": (_i, [_p, _i64, _i, _p, _p, _p]),
     "fdyn_agent_step_f64": (_i, [_i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _i64, _d, _i, _p, _p]),
     "fdyn_agent_step_mixed": (_i, [_i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _i64, _d, _i, _p, _p]),
     "fdyn_agent_step_f32": (_i, [_i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _i64, _d, _i, _p, _p]),

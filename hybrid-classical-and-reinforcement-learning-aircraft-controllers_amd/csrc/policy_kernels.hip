@@ -28,6 +28,7 @@ __device__ __forceinline__ uint16_t f2bf(float f)
 template <typename T> struct Vec8;
 template <> struct Vec8<float> {
     static __device__ __forceinline__ float scalar(float v) { return v; }
+    static __device__ __forceinline__ float round(float v) { return v; }
     static __device__ __forceinline__ void load(const float* p, float (&o)[VEC])
     {
         const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
@@ -41,6 +42,7 @@ template <> struct Vec8<float> {
 };
 template <> struct Vec8<uint16_t> {   // bf16 storage
     static __device__ __forceinline__ float scalar(uint16_t v) { return __uint_as_float(uint32_t(v) << 16); }
+    static __device__ __forceinline__ float round(float v) { return bf2f(f2bf(v)); }      // the value a store keeps
     static __device__ __forceinline__ void load(const uint16_t* p, float (&o)[VEC])
     {
         const uint4 a = *reinterpret_cast<const uint4*>(p);
@@ -132,57 +134,178 @@ lstm_cell_fwd_kernel(const GT* __restrict__ gates, const float* __restrict__ c_p
     }
 }
 
-// gradient of the cell update w.r.t. the pre-activation gates and c_prev
+// gradient of the cell update w.r.t. the pre-activation gates and c_prev.
+// A block owns `rows_per_block` consecutive rows and walks them in passes of 256 * VEC / H rows, every lane keeping its
+// column: with bias_ws != nullptr the lanes also sum their dgates over the passes, the block folds the passes' row slots
+// through LDS and writes ONE partial row [4H] to bias_ws[blockIdx.x] -- the bias gradient (column sums of dgates over all
+// rows of a BPTT pass) then costs a reduction over a few thousand partial rows instead of a second pass over the [rows, 4H]
+// tensor (fdyn_colsum: 5 % of a PPO iteration, rocprofv3).  No atomics: graph-replay safe and deterministic.
+// bias_ws needs 256 % (H / VEC) == 0 (lanes keep their column); without it any H % VEC == 0 works.
 template <typename GT>
 __global__ void __launch_bounds__(256)
 lstm_cell_bwd_kernel(const GT* act /*may alias dgates: every lane reads its 4 x 8 values before it writes them*/,
                      const float* __restrict__ c_prev, const float* __restrict__ c_new,
                      const GT* __restrict__ dh, const float* __restrict__ dc_next, GT* dgates,
-                     float* __restrict__ dc_prev, int64_t total_vec, int H,
+                     float* __restrict__ dc_prev, int64_t total_vec, int H, int64_t vecs_per_block, float* __restrict__ bias_ws,
                      const float* __restrict__ keep = nullptr /*[B]: the forward used keep * c_prev*/,
                      const GT* __restrict__ dh2 = nullptr /*second dh addend, row stride dh2_stride, scaled by dh2_keep*/,
                      int64_t dh2_stride = 0, const float* __restrict__ dh2_keep = nullptr)
+{
+    __shared__ float s_red[256 * VEC * 4];
+    const int hv = H / VEC;
+    float acc[4][VEC];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[g][k] = 0.0f;
+    const int64_t v0 = int64_t(blockIdx.x) * vecs_per_block;
+    for (int64_t vo = threadIdx.x; vo < vecs_per_block; vo += 256) {
+        const int64_t t = v0 + vo;
+        if (t >= total_vec) break;
+        const int64_t row = t / hv;
+        const int j = int(t - row * hv) * VEC;
+        const GT* a0 = act + row * 4 * H + j;
+        float ai[VEC], af[VEC], ag[VEC], ao[VEC], cp[VEC], cn[VEC], dhv[VEC], dcn[VEC];
+        float di[VEC], df[VEC], dg[VEC], dov[VEC], dcp[VEC];
+        Vec8<GT>::load(a0, ai); Vec8<GT>::load(a0 + H, af); Vec8<GT>::load(a0 + 2 * H, ag); Vec8<GT>::load(a0 + 3 * H, ao);
+        if (c_new) {
+            Vec8<float>::load(c_new + row * H + j, cn);
+        } else {                                              // zero-state cell whose c was not kept: c = i * g from the saved gates
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) cn[k] = ai[k] * ag[k];
+        }
+        Vec8<GT>::load(dh + row * H + j, dhv);
+        if (c_prev) Vec8<float>::load(c_prev + row * H + j, cp);
+        if (dc_next) Vec8<float>::load(dc_next + row * H + j, dcn);
+        const float kp = keep ? keep[row] : 1.0f;
+        if (dh2) {                                            // recurrent gradient from step t + 1, summed in fp32
+            float d2[VEC];
+            Vec8<GT>::load(dh2 + row * dh2_stride + j, d2);
+            const float k2 = dh2_keep ? dh2_keep[row] : 1.0f;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) dhv[k] += k2 * d2[k];
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            if (c_prev) cp[k] *= kp;
+            const float tc = tanhf_(cn[k]);
+            const float dc = dhv[k] * ao[k] * (1.0f - tc * tc) + (dc_next ? dcn[k] : 0.0f);
+            dov[k] = dhv[k] * tc * ao[k] * (1.0f - ao[k]);
+            di[k] = dc * ag[k] * ai[k] * (1.0f - ai[k]);
+            dg[k] = dc * ai[k] * (1.0f - ag[k] * ag[k]);
+            df[k] = c_prev ? dc * cp[k] * af[k] * (1.0f - af[k]) : 0.0f;
+            dcp[k] = dc * af[k] * kp;
+        }
+        GT* d0 = dgates + row * 4 * H + j;
+        Vec8<GT>::store(d0, di); Vec8<GT>::store(d0 + H, df); Vec8<GT>::store(d0 + 2 * H, dg); Vec8<GT>::store(d0 + 3 * H, dov);
+        if (dc_prev) Vec8<float>::store(dc_prev + row * H + j, dcp);
+        if (bias_ws) {                                        // the sums are of the values the weight-gradient GEMM will read
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                acc[0][k] += Vec8<GT>::round(di[k]); acc[1][k] += Vec8<GT>::round(df[k]);
+                acc[2][k] += Vec8<GT>::round(dg[k]); acc[3][k] += Vec8<GT>::round(dov[k]);
+            }
+        }
+    }
+    if (bias_ws) {                                            // [row slot][4H] -> one partial row per block
+        const int rs = threadIdx.x / hv, j = (threadIdx.x % hv) * VEC, rpp = 256 / hv;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) s_red[rs * 4 * H + g * H + j + k] = acc[g][k];
+        __syncthreads();
+        for (int c = threadIdx.x; c < 4 * H; c += 256) {
+            float t = 0.0f;
+            for (int q = 0; q < rpp; ++q) t += s_red[q * 4 * H + c];
+            bias_ws[int64_t(blockIdx.x) * 4 * H + c] = t;
+        }
+    }
+}
+
+// ---- the zero-state cell in the THREE-gate layout (i, g, o along the 3H axis): the features extractor's two LSTM layers.
+// The reference calls self.lstm(embedded) on a length-1 sequence without carried state (learned_controllers/networks/
+// lstm_policy.py:75-92): h = c = 0 going in, so the forget gate multiplies zero and its pre-activation, its saved activation,
+// its (zero) gradient and its rows of W_ih never need to exist -- a quarter of the layer's GEMM work and of these kernels'
+// traffic (the rollout's policy_fe64.hip drops it the same way).
+template <typename GT>
+__global__ void __launch_bounds__(256)
+lstm_cell0_fwd_kernel(const GT* __restrict__ gates /*[B][3H]*/, GT* __restrict__ h_out /*[B][H]*/, GT* act_out /*[B][3H] or null; may alias gates*/,
+                      int64_t total_vec, int H)
 {
     const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (t >= total_vec) return;
     const int hv = H / VEC;
     const int64_t row = t / hv;
     const int j = int(t - row * hv) * VEC;
-    const GT* a0 = act + row * 4 * H + j;
-    float ai[VEC], af[VEC], ag[VEC], ao[VEC], cp[VEC], cn[VEC], dhv[VEC], dcn[VEC];
-    float di[VEC], df[VEC], dg[VEC], dov[VEC], dcp[VEC];
-    Vec8<GT>::load(a0, ai); Vec8<GT>::load(a0 + H, af); Vec8<GT>::load(a0 + 2 * H, ag); Vec8<GT>::load(a0 + 3 * H, ao);
-    if (c_new) {
-        Vec8<float>::load(c_new + row * H + j, cn);
-    } else {                                              // zero-state cell whose c was not kept: c = i * g from the saved gates
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) cn[k] = ai[k] * ag[k];
-    }
-    Vec8<GT>::load(dh + row * H + j, dhv);
-    if (c_prev) Vec8<float>::load(c_prev + row * H + j, cp);
-    if (dc_next) Vec8<float>::load(dc_next + row * H + j, dcn);
-    const float kp = keep ? keep[row] : 1.0f;
-    if (dh2) {                                            // recurrent gradient from step t + 1, summed in fp32
-        float d2[VEC];
-        Vec8<GT>::load(dh2 + row * dh2_stride + j, d2);
-        const float k2 = dh2_keep ? dh2_keep[row] : 1.0f;
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) dhv[k] += k2 * d2[k];
-    }
+    const GT* g0 = gates + row * 3 * H + j;
+    float gi[VEC], gg[VEC], go[VEC], h[VEC];
+    Vec8<GT>::load(g0, gi); Vec8<GT>::load(g0 + H, gg); Vec8<GT>::load(g0 + 2 * H, go);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
-        if (c_prev) cp[k] *= kp;
-        const float tc = tanhf_(cn[k]);
-        const float dc = dhv[k] * ao[k] * (1.0f - tc * tc) + (dc_next ? dcn[k] : 0.0f);
-        dov[k] = dhv[k] * tc * ao[k] * (1.0f - ao[k]);
-        di[k] = dc * ag[k] * ai[k] * (1.0f - ai[k]);
-        dg[k] = dc * ai[k] * (1.0f - ag[k] * ag[k]);
-        df[k] = c_prev ? dc * cp[k] * af[k] * (1.0f - af[k]) : 0.0f;
-        dcp[k] = dc * af[k] * kp;
+        gi[k] = sigmoidf_(gi[k]); gg[k] = tanhf_(gg[k]); go[k] = sigmoidf_(go[k]);
+        h[k] = go[k] * tanhf_(gi[k] * gg[k]);
     }
-    GT* d0 = dgates + row * 4 * H + j;
-    Vec8<GT>::store(d0, di); Vec8<GT>::store(d0 + H, df); Vec8<GT>::store(d0 + 2 * H, dg); Vec8<GT>::store(d0 + 3 * H, dov);
-    if (dc_prev) Vec8<float>::store(dc_prev + row * H + j, dcp);
+    Vec8<GT>::store(h_out + row * H + j, h);
+    if (act_out) {
+        GT* a0 = act_out + row * 3 * H + j;
+        Vec8<GT>::store(a0, gi); Vec8<GT>::store(a0 + H, gg); Vec8<GT>::store(a0 + 2 * H, go);
+    }
+}
+
+// its gradient: dgates [B][3H] (may alias act) from the saved activations and dh; c = i * g is rebuilt (from the ROUNDED
+// saved gates, as the four-gate kernel does for a zero-state cell); bias partial sums as in lstm_cell_bwd_kernel.
+template <typename GT>
+__global__ void __launch_bounds__(256)
+lstm_cell0_bwd_kernel(const GT* act, const GT* __restrict__ dh, GT* dgates, int64_t total_vec, int H, int64_t vecs_per_block,
+                      float* __restrict__ bias_ws)
+{
+    __shared__ float s_red[256 * VEC * 3];
+    const int hv = H / VEC;
+    float acc[3][VEC];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[g][k] = 0.0f;
+    const int64_t v0 = int64_t(blockIdx.x) * vecs_per_block;
+    for (int64_t vo = threadIdx.x; vo < vecs_per_block; vo += 256) {
+        const int64_t t = v0 + vo;
+        if (t >= total_vec) break;
+        const int64_t row = t / hv;
+        const int j = int(t - row * hv) * VEC;
+        const GT* a0 = act + row * 3 * H + j;
+        float ai[VEC], ag[VEC], ao[VEC], dhv[VEC], di[VEC], dg[VEC], dov[VEC];
+        Vec8<GT>::load(a0, ai); Vec8<GT>::load(a0 + H, ag); Vec8<GT>::load(a0 + 2 * H, ao);
+        Vec8<GT>::load(dh + row * H + j, dhv);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const float tc = tanhf_(ai[k] * ag[k]);
+            const float dc = dhv[k] * ao[k] * (1.0f - tc * tc);
+            dov[k] = dhv[k] * tc * ao[k] * (1.0f - ao[k]);
+            di[k] = dc * ag[k] * ai[k] * (1.0f - ai[k]);
+            dg[k] = dc * ai[k] * (1.0f - ag[k] * ag[k]);
+        }
+        GT* d0 = dgates + row * 3 * H + j;
+        Vec8<GT>::store(d0, di); Vec8<GT>::store(d0 + H, dg); Vec8<GT>::store(d0 + 2 * H, dov);
+        if (bias_ws) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                acc[0][k] += Vec8<GT>::round(di[k]); acc[1][k] += Vec8<GT>::round(dg[k]); acc[2][k] += Vec8<GT>::round(dov[k]);
+            }
+        }
+    }
+    if (bias_ws) {
+        const int rs = threadIdx.x / hv, j = (threadIdx.x % hv) * VEC, rpp = 256 / hv;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) s_red[rs * 3 * H + g * H + j + k] = acc[g][k];
+        __syncthreads();
+        for (int c = threadIdx.x; c < 3 * H; c += 256) {
+            float t = 0.0f;
+            for (int q = 0; q < rpp; ++q) t += s_red[q * 3 * H + c];
+            bias_ws[int64_t(blockIdx.x) * 3 * H + c] = t;
+        }
+    }
 }
 
 // GAE(lambda) over a [T, N] rollout, one lane per env, scanning t = T-1 .. 0 (rewards/values/starts row-major [T][N])
@@ -428,6 +551,29 @@ colsum_final_kernel(const float* __restrict__ partial, int nb, int N, float* __r
     }
 }
 
+// stage 1.5 for MANY partial rows (the bias partials of the fused backward kernels: thousands of rows): block (x, y) sums rows
+// [64 y, 64 y + 64) of 32 adjacent columns -> mid [gridDim.y][N]; colsum_final_kernel finishes.  (The final kernel alone
+// would read the whole table with N / 32 blocks.)
+__global__ void __launch_bounds__(256)
+colsum_mid_kernel(const float* __restrict__ partial, int64_t nb, int N, float* __restrict__ mid)
+{
+    __shared__ float s[8][33];
+    const int cx = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    const int64_t r0 = int64_t(blockIdx.y) * 64, r1 = r0 + 64 < nb ? r0 + 64 : nb;
+    float a = 0.0f;
+    if (c < N)
+        for (int64_t b = r0 + sl; b < r1; b += 8) a += partial[b * N + c];
+    s[sl][cx] = a;
+    __syncthreads();
+    if (sl == 0 && c < N) {
+        float t = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += s[q][cx];
+        mid[int64_t(blockIdx.y) * N + c] = t;
+    }
+}
+
 // ws[0] += sum adv, ws[1] += sum adv^2
 __global__ void __launch_bounds__(256)
 adv_moments_kernel(const float* __restrict__ adv, int64_t M, float* __restrict__ ws)
@@ -613,10 +759,10 @@ int fdyn_lstm_cell_bwd(const void* act, int bf16, const float* c_prev, const flo
     const int64_t tv = B * (H / VEC);
     if (bf16)
         hipLaunchKernelGGL((lstm_cell_bwd_kernel<uint16_t>), dim3(blocks(tv)), dim3(256), 0, (hipStream_t)stream,
-                           (const uint16_t*)act, c_prev, c_new, (const uint16_t*)dh, dc_next, (uint16_t*)dgates, dc_prev, tv, H);
+                           (const uint16_t*)act, c_prev, c_new, (const uint16_t*)dh, dc_next, (uint16_t*)dgates, dc_prev, tv, H, int64_t(256), (float*)nullptr);
     else
         hipLaunchKernelGGL((lstm_cell_bwd_kernel<float>), dim3(blocks(tv)), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)act, c_prev, c_new, (const float*)dh, dc_next, (float*)dgates, dc_prev, tv, H);
+                           (const float*)act, c_prev, c_new, (const float*)dh, dc_next, (float*)dgates, dc_prev, tv, H, int64_t(256), (float*)nullptr);
     return int(hipGetLastError());
 }
 
@@ -639,22 +785,88 @@ int fdyn_lstm_seq_fwd(const void* gates, int gates_bf16, const float* c_prev, co
     return int(hipGetLastError());
 }
 
+static int seq_bwd_launch(const void* act, int bf16, const float* c_prev, const float* keep, const float* c_new, const void* dh,
+                          const void* dh2, int64_t dh2_stride, const float* dh2_keep, const float* dc_next, void* dgates,
+                          float* dc_prev, float* bias_ws, int64_t rows_per_block, int64_t B, int H, void* stream)
+{
+    if (B < 0 || H <= 0 || H % VEC || (dh2 && dh2_stride < H)) return FDYN_ERR_BAD_SIZE;
+    if (!act || !c_prev || !c_new || !dh || !dgates || !dc_prev) return FDYN_ERR_NULL;
+    const int hv = H / VEC;
+    if (bias_ws && (256 % hv || rows_per_block < 1 || (rows_per_block * hv) % 256)) return FDYN_ERR_BAD_SIZE;
+    if (B == 0) return FDYN_OK;
+    const int64_t tv = B * hv;
+    const int64_t vpb = bias_ws ? rows_per_block * hv : 256;
+    const unsigned nblk = unsigned((tv + vpb - 1) / vpb);
+    if (bf16)
+        hipLaunchKernelGGL((lstm_cell_bwd_kernel<uint16_t>), dim3(nblk), dim3(256), 0, (hipStream_t)stream,
+                           (const uint16_t*)act, c_prev, c_new, (const uint16_t*)dh, dc_next, (uint16_t*)dgates, dc_prev, tv, H, vpb, bias_ws,
+                           keep, (const uint16_t*)dh2, dh2_stride, dh2_keep);
+    else
+        hipLaunchKernelGGL((lstm_cell_bwd_kernel<float>), dim3(nblk), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)act, c_prev, c_new, (const float*)dh, dc_next, (float*)dgates, dc_prev, tv, H, vpb, bias_ws,
+                           keep, (const float*)dh2, dh2_stride, dh2_keep);
+    return int(hipGetLastError());
+}
+
 int fdyn_lstm_seq_bwd(const void* act, int bf16, const float* c_prev, const float* keep, const float* c_new, const void* dh,
                       const void* dh2, int64_t dh2_stride, const float* dh2_keep, const float* dc_next, void* dgates,
                       float* dc_prev, int64_t B, int H, void* stream)
 {
-    if (B < 0 || H <= 0 || H % VEC || (dh2 && dh2_stride < H)) return FDYN_ERR_BAD_SIZE;
-    if (!act || !c_prev || !c_new || !dh || !dgates || !dc_prev) return FDYN_ERR_NULL;
+    return seq_bwd_launch(act, bf16, c_prev, keep, c_new, dh, dh2, dh2_stride, dh2_keep, dc_next, dgates, dc_prev, nullptr, 0, B, H, stream);
+}
+
+int fdyn_lstm_seq_bwd_bsum(const void* act, int bf16, const float* c_prev, const float* keep, const float* c_new, const void* dh,
+                           const void* dh2, int64_t dh2_stride, const float* dh2_keep, const float* dc_next, void* dgates,
+                           float* dc_prev, float* bias_ws, int64_t rows_per_block, int64_t B, int H, void* stream)
+{
+    if (!bias_ws) return FDYN_ERR_NULL;
+    return seq_bwd_launch(act, bf16, c_prev, keep, c_new, dh, dh2, dh2_stride, dh2_keep, dc_next, dgates, dc_prev, bias_ws, rows_per_block,
+                          B, H, stream);
+}
+
+int fdyn_lstm_cell0_fwd(const void* gates, int bf16, void* h_out, void* act_out, int64_t B, int H, void* stream)
+{
+    if (B < 0 || H <= 0 || H % VEC) return FDYN_ERR_BAD_SIZE;
+    if (!gates || !h_out) return FDYN_ERR_NULL;
     if (B == 0) return FDYN_OK;
     const int64_t tv = B * (H / VEC);
     if (bf16)
-        hipLaunchKernelGGL((lstm_cell_bwd_kernel<uint16_t>), dim3(blocks(tv)), dim3(256), 0, (hipStream_t)stream,
-                           (const uint16_t*)act, c_prev, c_new, (const uint16_t*)dh, dc_next, (uint16_t*)dgates, dc_prev, tv, H, keep,
-                           (const uint16_t*)dh2, dh2_stride, dh2_keep);
+        hipLaunchKernelGGL((lstm_cell0_fwd_kernel<uint16_t>), dim3(blocks(tv)), dim3(256), 0, (hipStream_t)stream,
+                           (const uint16_t*)gates, (uint16_t*)h_out, (uint16_t*)act_out, tv, H);
     else
-        hipLaunchKernelGGL((lstm_cell_bwd_kernel<float>), dim3(blocks(tv)), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)act, c_prev, c_new, (const float*)dh, dc_next, (float*)dgates, dc_prev, tv, H, keep,
-                           (const float*)dh2, dh2_stride, dh2_keep);
+        hipLaunchKernelGGL((lstm_cell0_fwd_kernel<float>), dim3(blocks(tv)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)gates, (float*)h_out, (float*)act_out, tv, H);
+    return int(hipGetLastError());
+}
+
+int fdyn_lstm_cell0_bwd(const void* act, int bf16, const void* dh, void* dgates, float* bias_ws, int64_t rows_per_block,
+                        int64_t B, int H, void* stream)
+{
+    if (B < 0 || H <= 0 || H % VEC) return FDYN_ERR_BAD_SIZE;
+    if (!act || !dh || !dgates) return FDYN_ERR_NULL;
+    const int hv = H / VEC;
+    if (bias_ws && (256 % hv || rows_per_block < 1 || (rows_per_block * hv) % 256)) return FDYN_ERR_BAD_SIZE;
+    if (B == 0) return FDYN_OK;
+    const int64_t tv = B * hv;
+    const int64_t vpb = bias_ws ? rows_per_block * hv : 256;
+    const unsigned nblk = unsigned((tv + vpb - 1) / vpb);
+    if (bf16)
+        hipLaunchKernelGGL((lstm_cell0_bwd_kernel<uint16_t>), dim3(nblk), dim3(256), 0, (hipStream_t)stream,
+                           (const uint16_t*)act, (const uint16_t*)dh, (uint16_t*)dgates, tv, H, vpb, bias_ws);
+    else
+        hipLaunchKernelGGL((lstm_cell0_bwd_kernel<float>), dim3(nblk), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)act, (const float*)dh, (float*)dgates, tv, H, vpb, bias_ws);
+    return int(hipGetLastError());
+}
+
+int fdyn_colsum_partials(const float* partial, int64_t nb, int N, float* out, float* ws_mid, void* stream)
+{
+    if (nb < 1 || N <= 0 || nb > (int64_t(1) << 30)) return FDYN_ERR_BAD_SIZE;
+    if (!partial || !out || !ws_mid) return FDYN_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nmid = (nb + 63) / 64;
+    hipLaunchKernelGGL(colsum_mid_kernel, dim3((N + 31) / 32, unsigned(nmid)), dim3(256), 0, st, partial, nb, N, ws_mid);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 31) / 32), dim3(256), 0, st, ws_mid, int(nmid), N, out);
     return int(hipGetLastError());
 }
 

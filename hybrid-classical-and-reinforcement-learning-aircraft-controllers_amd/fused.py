@@ -163,6 +163,131 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], min_rows
     return torch.nn.functional.linear(x, w, b)
 
 
+def _bsum_rows_per_block(rows: int, H: int) -> int:
+    """Rows a block of the bias-summing backward kernels owns (0 = this H cannot keep one column per lane)."""
+    hv = H // 8
+    if H % 8 or hv == 0 or 256 % hv:
+        return 0
+    return (256 // hv) * (16 if rows >= 262144 else 4)
+
+
+def colsum_partials(partial: torch.Tensor) -> torch.Tensor:
+    """partial [nb, N] fp32 (one row per block of a bias-summing backward kernel) -> [N] column sums, no atomics."""
+    nb, N = partial.shape
+    lib = _lib.load()
+    out = torch.empty(N, dtype=torch.float32, device=partial.device)
+    mid = torch.empty(((nb + 63) // 64, N), dtype=torch.float32, device=partial.device)
+    _lib.check(lib.fdyn_colsum_partials(partial.data_ptr(), nb, N, out.data_ptr(), mid.data_ptr(), _lib.current_stream()),
+               "colsum_partials")
+    return out
+
+
+class _ZeroStateLayerFn(torch.autograd.Function):
+    """One LSTM layer of the features extractor, h = sigmoid(o) tanh(sigmoid(i) tanh(g)) with [i g o] = x W3^T + b3, as ONE
+    autograd node in the THREE-gate layout: the reference runs these layers from h = c = 0 on every call
+    (learned_controllers/networks/lstm_policy.py:75-92), so the forget gate multiplies zero -- its rows of W_ih, its
+    pre-activation, its saved activation and its (exactly zero) gradient are never formed: a quarter less GEMM work (forward,
+    dX and dW) and point-wise traffic.  Backward: one point-wise launch that also leaves the bias gradient as per-block partial
+    sums (no second pass over [M, 3H]), dX GEMM, split-K dW GEMM; the f rows of dW_ih / db come back as zeros."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, b_ih, b_hh):
+        lib = _lib.load()
+        H = w_ih.shape[0] // 4
+        dt = x.dtype
+        bf16 = dt == torch.bfloat16
+        assert bf16 or dt == torch.float32
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        M = x2.shape[0]
+        with torch.autocast("cuda", enabled=False):
+            w3 = torch.cat([w_ih[:H], w_ih[2 * H:]]).to(dt)                                   # rows of i, g, o
+            b = b_ih + b_hh
+            b3 = torch.cat([b[:H], b[2 * H:]]).to(dt)
+            gates = torch.addmm(b3, x2, w3.t())                                               # [M, 3H], bias in the epilogue
+        need = any(ctx.needs_input_grad)
+        h = torch.empty((M, H), dtype=dt, device=x.device)
+        # the activated gates overwrite the pre-activations in place
+        _lib.check(lib.fdyn_lstm_cell0_fwd(gates.data_ptr(), int(bf16), h.data_ptr(), gates.data_ptr() if need else None, M, H,
+                                           _lib.current_stream()), "lstm_cell0_fwd")
+        if need:
+            ctx.save_for_backward(x2, w3, gates)
+            ctx.H, ctx.xshape, ctx.dtypes = H, x.shape, (w_ih.dtype, b_ih.dtype, b_hh.dtype)
+        return h.view(*x.shape[:-1], H)
+
+    @staticmethod
+    def backward(ctx, dh):
+        lib = _lib.load()
+        x2, w3, act = ctx.saved_tensors
+        H, M, dt, dev = ctx.H, act.shape[0], act.dtype, act.device
+        bf16 = dt == torch.bfloat16
+        dh = dh.reshape(M, H).to(dt).contiguous()
+        rpb = _bsum_rows_per_block(M, H)
+        ws = torch.empty(((M + rpb - 1) // rpb, 3 * H), dtype=torch.float32, device=dev) if rpb else None
+        _lib.check(lib.fdyn_lstm_cell0_bwd(act.data_ptr(), int(bf16), dh.data_ptr(), act.data_ptr(), _lib.ptr(ws), rpb, M, H,
+                                           _lib.current_stream()), "lstm_cell0_bwd")
+        dg = act                                                                              # dgates, in place
+        needs = ctx.needs_input_grad
+        with torch.autocast("cuda", enabled=False):
+            dx = (dg @ w3).view(ctx.xshape) if needs[0] else None
+            dw = db = None
+            if needs[1]:
+                dw3 = wgrad_splitk(dg, x2)                                                    # fp32 [3H, K]
+                dw = torch.zeros((4 * H, x2.shape[1]), dtype=torch.float32, device=dev)
+                dw[:H].copy_(dw3[:H]); dw[2 * H:].copy_(dw3[H:])
+                dw = dw.to(ctx.dtypes[0])
+            if needs[2] or needs[3]:
+                db3 = colsum_partials(ws) if rpb else colsum(dg)
+                db = torch.zeros(4 * H, dtype=torch.float32, device=dev)
+                db[:H].copy_(db3[:H]); db[2 * H:].copy_(db3[H:])
+        return dx, dw, (db.to(ctx.dtypes[1]) if needs[2] else None), (db.to(ctx.dtypes[2]) if needs[3] else None)
+
+
+def zero_state_lstm_layer(x: torch.Tensor, w_ih: torch.Tensor, b_ih: torch.Tensor, b_hh: torch.Tensor) -> torch.Tensor:
+    """x [..., K] -> h [..., H] of an nn.LSTM layer stepped once from zero state (the features extractor's layers)."""
+    rows = x.numel() // max(x.shape[-1], 1)
+    if x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and rows >= linear.__defaults__[0]:
+        return _ZeroStateLayerFn.apply(x, w_ih, b_ih, b_hh)
+    return lstm_cell(linear(x, w_ih, b_ih + b_hh), None, need_c=False)[0]       # four-gate layout: CPU, small batches
+
+
+class _LinearReLUFn(torch.autograd.Function):
+    """relu(x W^T + b) with the bias and the ReLU in the GEMM epilogue (hipBLASLt through torch._addmm_activation), split-K
+    weight gradient, ReLU mask applied to dY in one launch."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, dt):
+        x2 = x.reshape(-1, x.shape[-1]).to(dt).contiguous()
+        with torch.autocast("cuda", enabled=False):
+            wd = w.to(dt)
+            y = torch._addmm_activation(b.to(dt), x2, wd.t())
+        ctx.save_for_backward(x2, wd, y)
+        ctx.xshape, ctx.dtypes = x.shape, (x.dtype, w.dtype, b.dtype)
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wd, y = ctx.saved_tensors
+        needs = ctx.needs_input_grad
+        with torch.autocast("cuda", enabled=False):
+            dy2 = torch.ops.aten.threshold_backward(dy.reshape(y.shape).to(y.dtype).contiguous(), y, 0)
+            dx = (dy2 @ wd).view(ctx.xshape).to(ctx.dtypes[0]) if needs[0] else None
+            dw = wgrad_splitk(dy2, x2).to(ctx.dtypes[1]) if needs[1] else None
+            db = colsum(dy2).to(ctx.dtypes[2]) if needs[2] else None
+        return dx, dw, db, None
+
+
+def linear_relu(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, min_rows: Optional[int] = None) -> torch.Tensor:
+    """relu(F.linear(x, w, b)) for the training path; tall GPU inputs take the fused epilogue + split-K weight gradient
+    (min_rows: as fused.linear, whose default it follows)."""
+    rows = x.numel() // max(x.shape[-1], 1)
+    min_rows = linear.__defaults__[0] if min_rows is None else min_rows
+    if x.is_cuda and b is not None and rows >= min_rows and torch.is_grad_enabled() and (w.requires_grad or x.requires_grad):
+        dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+        if dt in (torch.bfloat16, torch.float32) and (dt != torch.float32 or (w.dtype == dt and x.dtype == dt)):
+            return _LinearReLUFn.apply(x, w, b, dt)
+    return torch.relu(linear(x, w, b, min_rows))
+
+
 class DeferredWgrad:
     """Weight gradient of a linear applied once per time step of a recurrence (BPTT): every step's backward stores its
     dY in slot t and returns only dX; when the backward pass ends, ONE split-K batched GEMM over all T*B rows gives
@@ -280,15 +405,23 @@ class _LSTMSequenceFn(torch.autograd.Function):
         dcat = torch.empty((T, G, B, K), dtype=dt, device=dev)
         dc = [torch.empty((G, B, H), dtype=torch.float32, device=dev) for _ in range(2)]
         st, R, esz = _lib.current_stream(), G * B, x_all.element_size()
+        # one cell per node: the point-wise kernel also leaves the bias gradient as per-block partial sums (no second pass
+        # over the [T*B, 4H] dgates); several cells in one node keep the grouped column sum below
+        rpb = _bsum_rows_per_block(R, H) if (G == 1 and any(ctx.needs_input_grad[4:])) else 0
+        nblk = (R + rpb - 1) // rpb if rpb else 0
+        bws = torch.empty((T, nblk, 4 * H), dtype=torch.float32, device=dev) if rpb else None
         for t in range(T - 1, -1, -1):
             last = t == T - 1
             # dgates overwrite the saved activations in place: act becomes dY for the weight gradient below
-            _lib.check(lib.fdyn_lstm_seq_bwd(act[t].data_ptr(), int(bf16), c_all[t].data_ptr(), keep_rows[t].data_ptr(),
-                                             c_all[t + 1].data_ptr(), dh_seq[t].data_ptr(),
-                                             None if last else dcat[t + 1].data_ptr() + kx * esz, K,
-                                             None if last else keep_rows[t + 1].data_ptr(),
-                                             None if last else dc[(t + 1) & 1].data_ptr(), act[t].data_ptr(),
-                                             dc[t & 1].data_ptr(), R, H, st), "lstm_seq_bwd")
+            args = (act[t].data_ptr(), int(bf16), c_all[t].data_ptr(), keep_rows[t].data_ptr(),
+                    c_all[t + 1].data_ptr(), dh_seq[t].data_ptr(),
+                    None if last else dcat[t + 1].data_ptr() + kx * esz, K,
+                    None if last else keep_rows[t + 1].data_ptr(),
+                    None if last else dc[(t + 1) & 1].data_ptr(), act[t].data_ptr(), dc[t & 1].data_ptr())
+            if rpb:
+                _lib.check(lib.fdyn_lstm_seq_bwd_bsum(*args, bws[t].data_ptr(), rpb, R, H, st), "lstm_seq_bwd_bsum")
+            else:
+                _lib.check(lib.fdyn_lstm_seq_bwd(*args, R, H, st), "lstm_seq_bwd")
             torch.bmm(act[t], w, out=dcat[t])
         needs = ctx.needs_input_grad
         grads = [None] * (4 * G)
@@ -297,7 +430,7 @@ class _LSTMSequenceFn(torch.autograd.Function):
             part = _bmm_f32(act.view(T * G, B, 4 * H).transpose(1, 2), x_all.view(T * G, B, K))     # [T*G, 4H, K]
             ones = torch.ones((1, T), dtype=part.dtype, device=dev)
             dw = torch.mm(ones, part.view(T, G * 4 * H * K)).view(G, 4 * H, K)
-            db = colsum(act.view(T * G * B, 4 * H), B, G).view(G, 4 * H)
+            db = colsum_partials(bws.view(T * nblk, 4 * H)).view(1, 4 * H) if rpb else colsum(act.view(T * G * B, 4 * H), B, G).view(G, 4 * H)
             d = ctx.param_dtypes
             for g in range(G):
                 if needs[4 + 4 * g]:

@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fused import DeferredWgrad, deferred_linear, linear, lstm_cell, lstm_sequence
+from .fused import DeferredWgrad, deferred_linear, linear, linear_relu, lstm_cell, lstm_sequence, zero_state_lstm_layer
 
 OBS_DIM, ACT_DIM = 18, 4
 
@@ -56,13 +56,21 @@ def _lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh):
 
 
 def _lstm_zero_state_layer(x, w_ih, b_ih, b_hh):
-    return lstm_cell(linear(x, w_ih, b_ih + b_hh), None, need_c=False)[0]
+    return zero_state_lstm_layer(x, w_ih, b_ih, b_hh)
 
 
 def _run_seq(seq, x):
-    """nn.Sequential of Linear / ReLU, with the Linears routed through fused.linear (split-K weight gradients)."""
-    for m in seq:
+    """nn.Sequential of Linear / ReLU, with the Linears routed through fused.linear (split-K weight gradients) and a
+    Linear + ReLU pair through fused.linear_relu (bias + ReLU in the GEMM epilogue)."""
+    mods, i = list(seq), 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Linear) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU) and m.bias is not None:
+            x = linear_relu(x, m.weight, m.bias)
+            i += 2
+            continue
         x = linear(x, m.weight, m.bias) if isinstance(m, nn.Linear) else m(x)
+        i += 1
     return x
 
 

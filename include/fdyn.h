@@ -36,7 +36,8 @@
  * Policy side (the reference delegates these to torch.nn.LSTM / SB3's PPO, which are not in its tree):
  *   fdyn_policy_features, fdyn_lstm_cell_mfma, fdyn_policy_heads, fdyn_gaussian_head   rollout: LSTM cell / output heads of
  *                          learned_controllers/networks/lstm_policy.py:13-136 (+ sb3_contrib's actor / critic LSTMs)
- *   fdyn_lstm_cell_fwd/_bwd, fdyn_lstm_seq_fwd/_bwd              BPTT point-wise cell update and its gradient
+ *   fdyn_lstm_cell_fwd/_bwd, fdyn_lstm_seq_fwd/_bwd(_bsum),      BPTT point-wise cell update and its gradient (bias sums folded in),
+ *   fdyn_lstm_cell0_fwd/_bwd, fdyn_colsum_partials                the zero-state three-gate layout of the features extractor
  *   fdyn_gae, fdyn_ppo_loss, fdyn_colsum                         GAE(lambda), clipped-surrogate loss + gradient, bias gradients
  *                          (SB3 PPO.train semantics driven by learned_controllers/train_rate.py:128-147; parity unpinned --
  *                          SB3 is absent -- and checked against the same arithmetic in plain torch)
@@ -181,6 +182,23 @@ int fdyn_lstm_seq_fwd(const void* gates, int gates_bf16, const float* c_prev, co
 int fdyn_lstm_seq_bwd(const void* act, int bf16, const float* c_prev, const float* keep, const float* c_new, const void* dh,
                       const void* dh2, int64_t dh2_stride, const float* dh2_keep, const float* dc_next, void* dgates,
                       float* dc_prev, int64_t B, int H, void* stream);
+/* The same backward step with the BIAS GRADIENT folded in: every block owns rows_per_block consecutive rows, sums its dgates
+ * (the rounded values it stores) per column and writes one partial row to bias_ws [ceil(B / rows_per_block)][4H]; the partial
+ * rows of all steps of a BPTT pass are then reduced by fdyn_colsum_partials instead of a second pass over [T*B][4H].
+ * Needs 256 % (H / 8) == 0 and (rows_per_block * H / 8) % 256 == 0. */
+int fdyn_lstm_seq_bwd_bsum(const void* act, int bf16, const float* c_prev, const float* keep, const float* c_new, const void* dh,
+                           const void* dh2, int64_t dh2_stride, const float* dh2_keep, const float* dc_next, void* dgates,
+                           float* dc_prev, float* bias_ws, int64_t rows_per_block, int64_t B, int H, void* stream);
+/* Zero-state cell in the THREE-gate layout (i, g, o along 3H): the features extractor's LSTM layers, which the reference runs
+ * on a length-1 sequence without carried state (learned_controllers/networks/lstm_policy.py:75-92), so the forget gate
+ * multiplies zero and neither its pre-activation nor its gradient exists.  fwd: gates [B][3H] (bias added by the GEMM) ->
+ * h_out [B][H], act_out [B][3H] activated gates (NULL = not kept; may alias gates).  bwd: act, dh -> dgates [B][3H] (may alias
+ * act); bias_ws as above with rows of 3H floats, or NULL. */
+int fdyn_lstm_cell0_fwd(const void* gates, int bf16, void* h_out, void* act_out, int64_t B, int H, void* stream);
+int fdyn_lstm_cell0_bwd(const void* act, int bf16, const void* dh, void* dgates, float* bias_ws, int64_t rows_per_block,
+                        int64_t B, int H, void* stream);
+/* out [N] = column sums of nb partial rows [nb][N] fp32 (two stages, no atomics); ws_mid [ceil(nb / 64)][N]. */
+int fdyn_colsum_partials(const float* partial, int64_t nb, int N, float* out, float* ws_mid, void* stream);
 /* Reductions of the PPO update, self-contained so that a hipGraph replay recomputes them (accumulators are cleared by a
  * kernel of the same launch sequence).  fdyn_colsum: out [N] fp32 = column sums of x [M][N] (bf16 or fp32), two stages
  * through ws [fdyn_colsum_ws_floats(...)], no atomics: bias gradients.  n_groups > 1: rows come in segments of group_rows,

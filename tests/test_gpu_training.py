@@ -333,6 +333,41 @@ def test_gaussian_head_statistics_and_logprob():
     assert torch.equal(d, mean.float())
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-5), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("M", [8200, 300000])
+def test_zero_state_layer_three_gate_matches_plain_torch_fp32(dtype, tol, M):
+    """The features extractor's LSTM layer as one node in the three-gate layout (fused.zero_state_lstm_layer: no forget gate,
+    bias gradient from per-block partial sums, split-K dW) against nn.LSTM's arithmetic in plain fp32 torch on the same
+    (rounded) inputs: h, dX, dW_ih (f rows exactly zero), db_ih = db_hh."""
+    from hcrl_amd import fused
+    torch.manual_seed(11)
+    K, H = 128, 256
+    x = (torch.randn(M, K, device="cuda") * 0.7).to(dtype)
+    w = (torch.randn(4 * H, K, device="cuda") * 0.1).requires_grad_()
+    bi, bh = (torch.randn(4 * H, device="cuda") * 0.1).requires_grad_(), (torch.randn(4 * H, device="cuda") * 0.1).requires_grad_()
+    wh = torch.randn(M, H, device="cuda") / M ** 0.5
+    xr = x.detach().float().requires_grad_()
+    wr = w.detach().to(dtype).float().requires_grad_()              # the layer multiplies in `dtype`
+    bsum = (bi + bh).detach().to(dtype).float()
+    br = bsum.clone().requires_grad_()
+    g = xr @ wr.t() + br
+    if dtype == torch.bfloat16:
+        g = g + (g.detach().to(dtype).float() - g.detach())        # the GEMM result is stored in bf16: same values, gradient of g
+    i, f, gg, o = g.chunk(4, -1)
+    h_ref = torch.sigmoid(o) * torch.tanh(torch.sigmoid(i) * torch.tanh(gg))
+    (h_ref * wh).sum().backward()
+    xq = x.detach().clone().requires_grad_()
+    h = fused.zero_state_lstm_layer(xq, w, bi, bh)
+    assert h.dtype == dtype and h.shape == (M, H)
+    (h.float() * wh).sum().backward()
+    assert float((h.float() - h_ref).abs().max()) < tol
+    rel = lambda a, b: float((a.float() - b).norm() / (b.norm() + 1e-20))      # noqa: E731
+    assert rel(xq.grad, xr.grad) < tol * 2
+    assert rel(w.grad, wr.grad) < tol * 2 and float(w.grad[H:2 * H].abs().max()) == 0.0
+    assert rel(bi.grad, br.grad) < tol * 2 and torch.equal(bi.grad, bh.grad) and float(bi.grad[H:2 * H].abs().max()) == 0.0
+    assert float(wr.grad[H:2 * H].abs().max()) == 0.0              # the reference agrees: the forget gate has no gradient
+
+
 @pytest.mark.parametrize("dtype,tol", [(None, 2e-4), (torch.bfloat16, 6e-2)])
 def test_deferred_splitk_weight_gradients_match_plain_autograd(dtype, tol):
     """The BPTT path with deferred / split-K weight gradients (fused.DeferredWgrad, fused.linear) against plain autograd
