@@ -115,13 +115,19 @@ __device__ __forceinline__ void sched_mfma_valu()
 // (KC + 8) bf16) is therefore moved as 64 * (KC/8 + 1) slots, the pad slot of each row re-reading the row's last vector.
 // Wave w issues slot groups w, w + 4, ... -- every wave the SAME number NG (the surplus re-issues a group: a duplicate write of
 // the same bytes), so that each wait can say exactly how many younger operations may stay in flight.
-template <int KX, int KH>
+template <int KX, int KH, bool TRAIN>
 __global__ void __launch_bounds__(256, 2)
 lstm_cell_mfma_dma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const uint16_t* __restrict__ h_prev /*[B][KH] bf16*/,
                       const float* __restrict__ c_prev /*[B][H]*/, const float* __restrict__ keep /*[B] or null*/,
                       const uint16_t* __restrict__ W /*[4H][KX+KH] bf16*/, const float* __restrict__ bias /*[4H]*/,
                       uint16_t* __restrict__ h_out /*[B][H] bf16*/, float* __restrict__ c_out /*[B][H]*/,
-                      float* __restrict__ h_out_f32 /*[B][H] or null*/, int64_t B, int H, int split)
+                      float* __restrict__ h_out_f32 /*[B][H] or null*/, int64_t B, int H, int split,
+                      // BPTT forward (all null / 0 in the rollout): the activated gates for the backward pass, and h' * keep_next
+                      // packed into the recurrent columns of the next step's [x | h] input row
+                      uint16_t* __restrict__ act_out = nullptr /*[B][act_gates * H] bf16: sigmoid(i), [sigmoid(f),] tanh(g), sigmoid(o)*/,
+                      int act_gates = 4 /*4: (i, f, g, o); 3: (i, g, o), zero-state layers*/,
+                      uint16_t* __restrict__ h_next = nullptr /*row stride next_stride elements*/, int64_t next_stride = 0,
+                      const float* __restrict__ keep_next = nullptr /*[B] or null*/)
 {
     constexpr int K = KX + KH;
     constexpr int KSTEPS = K / 16;
@@ -142,6 +148,7 @@ lstm_cell_mfma_dma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const
     constexpr int PD = 2;                                 // k-steps a B-operand LDS read runs ahead of its MFMAs
     __shared__ __attribute__((aligned(16))) uint16_t s_w[3 * BUF];
     __shared__ float s_keep[BM];
+    __shared__ float s_keepn[BM];                         // keep_next of the block's rows (BPTT forward)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hf = lane >> 5;
@@ -191,6 +198,12 @@ lstm_cell_mfma_dma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const
             s_keep[i] = (keep && b < B) ? keep[b] : 1.0f;
         }
     }
+    if (TRAIN && h_next) {
+        for (int i = tid; i < BM; i += THREADS) {
+            const int64_t b = int64_t(blockIdx.x) * BM + i;
+            s_keepn[i] = (keep_next && b < B) ? keep_next[b] : 1.0f;
+        }
+    }
     // ---- A slab -> registers (masked h part).  Branch-free: rows past B read row B-1 (their results are never stored) and
     // the episode-start mask is a select, so all K/16 loads are in flight together (a guarded load per k-step makes
     // hipcc branch and drain vmcnt around each one).
@@ -232,11 +245,18 @@ lstm_cell_mfma_dma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const
     float* c_base = c_out ? c_out + uwave_off : nullptr;
     float* h32_base = h_out_f32 ? h_out_f32 + uwave_off : nullptr;
     uint16_t* h_base = h_out + uwave_off;
+    const uint32_t aH = uint32_t(act_gates * H);          // activated-gate row length
+    // TRAIN is a separate instantiation: the rollout's kernel must not pay registers for these (it sits at the 256-register edge)
+    uint16_t* act_base = (TRAIN && act_out) ? act_out + (urow0 < B ? urow0 : 0) * int64_t(aH) : nullptr;
+    uint16_t* hn_base = (TRAIN && h_next) ? h_next + (urow0 < B ? urow0 : 0) * next_stride : nullptr;
+    const uint32_t aoff = uint32_t(hf * 4) * aH, noff = uint32_t(hf * 4) * uint32_t(next_stride);
+    const uint32_t ag_f = uint32_t(H), ag_g = uint32_t((act_gates - 2) * H), ag_o = uint32_t((act_gates - 1) * H);     // gate i at 0
     const uint32_t uoff = uint32_t(hf * 4 * H), uH = uint32_t(H);          // + the slice's hidden unit per use
     auto ld_f32 = [](const float* b, uint32_t boff) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(b) + boff); };
     auto st_f32 = [](float* b, uint32_t boff, float v) { *reinterpret_cast<float*>(reinterpret_cast<char*>(b) + boff) = v; };
     auto st_u16 = [](uint16_t* b, uint32_t boff, uint16_t v) { *reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(b) + boff) = v; };
-    const int st_per_elem = 1 + (c_base != nullptr) + (h32_base != nullptr);       // store instructions one epilogue element issues
+    // store instructions one (f, o) epilogue element issues
+    const int st_per_elem = 1 + (c_base != nullptr) + (h32_base != nullptr) + (act_base ? (RECUR ? 2 : 1) : 0) + (hn_base != nullptr);
 
     // ---- VMEM bookkeeping for the counted waits (all wave-uniform)
     int after_last_dma = 0;    // operations issued after the most recent chunk request
@@ -256,8 +276,10 @@ lstm_cell_mfma_dma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const
         constexpr bool FAST = decltype(fast_c)::value;
         const int lr = (e & 3) + 8 * (e >> 2) + 4 * hf;
         float c = ig[e];
-        if (RECUR) c += sigmoid_b(accB0[e], pbf) * (s_keep[wave * 32 + lr] * cp[e]);
-        const float hv = sigmoid_b(accB1[e], pbo) * tanh_(c);
+        const float sf = RECUR ? sigmoid_b(accB0[e], pbf) : 0.0f;
+        if (RECUR) c += sf * (s_keep[wave * 32 + lr] * cp[e]);
+        const float so = sigmoid_b(accB1[e], pbo);
+        const float hv = so * tanh_(c);
         const uint32_t off = uoff + pcol + uint32_t((e & 3) + 8 * (e >> 2)) * uH;
         if constexpr (FAST) {
             st_f32(c_base, off * 4u, c);
@@ -266,6 +288,14 @@ lstm_cell_mfma_dma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const
             if (c_base) st_f32(c_base, off * 4u, c);
             st_u16(h_base, off * 2u, f2bf(hv));
             if (h32_base) st_f32(h32_base, off * 4u, hv);
+            if (TRAIN && act_base) {
+                const uint32_t ao = aoff + pcol + uint32_t((e & 3) + 8 * (e >> 2)) * aH;
+                if (RECUR) st_u16(act_base, (ao + ag_f) * 2u, f2bf(sf));
+                st_u16(act_base, (ao + ag_o) * 2u, f2bf(so));
+            }
+            if (TRAIN && hn_base)
+                st_u16(hn_base, (noff + pcol + uint32_t((e & 3) + 8 * (e >> 2)) * uint32_t(next_stride)) * 2u,
+                       f2bf(hv * s_keepn[wave * 32 + lr]));
         }
     };
 
@@ -370,9 +400,22 @@ lstm_cell_mfma_dma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const
             }
             // C/D map of a 32x32 tile: col = lane & 31 (hidden unit), row = (e & 3) + 8 (e >> 2) + 4 hf
 #pragma unroll
-            for (int e = ch * EPC; e < (ch + 1) * EPC; ++e) ig[e] = sigmoid_b(accA0[e], bi) * tanh_b(accA1[e], bg);
+            for (int e = ch * EPC; e < (ch + 1) * EPC; ++e) {
+                const float si = sigmoid_b(accA0[e], bi), tg = tanh_b(accA1[e], bg);
+                ig[e] = si * tg;
+                if constexpr (TRAIN && !decltype(fast_c)::value) {
+                    const int lr = (e & 3) + 8 * (e >> 2) + 4 * hf;
+                    if (act_base && (full || lr < rows_left)) {
+                        const uint32_t ao = aoff + col + uint32_t((e & 3) + 8 * (e >> 2)) * aH;
+                        st_u16(act_base, ao * 2u, f2bf(si));
+                        st_u16(act_base, (ao + ag_g) * 2u, f2bf(tg));
+                    }
+                }
+            }
             if constexpr (decltype(fast_c)::value) {
                 sched_mfma_valu<(RECUR ? 2 : 1) * KC_STEPS, (EPC * 11 + 2 * KC_STEPS - 1) / (2 * KC_STEPS) + (RECUR ? 0 : 4), 0>();
+            } else if (TRAIN && act_base && (full || rows_left > 0)) {
+                FD_ISSUED(EPC * 2)
             }
             FD_BLOCK_END
         }
@@ -382,7 +425,7 @@ lstm_cell_mfma_dma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const
     };
 
     using T_ = std::true_type; using F_ = std::false_type;
-    const bool fast = full && c_base != nullptr && h32_base == nullptr;     // wave-uniform
+    const bool fast = !TRAIN && full && c_base != nullptr && h32_base == nullptr;     // wave-uniform
     if (fast) {
         slice(0, F_{}, T_{});
         for (int si = 1; si < n_slices; ++si) slice(si, T_{}, T_{});
@@ -398,7 +441,8 @@ lstm_cell_mfma_dma_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const
 
 template <int KX, int KH>
 int launch(const void* x, const void* h_prev, const float* c_prev, const float* keep, const void* W, const float* bias,
-           void* h_out, float* c_out, float* h_out_f32, int64_t B, int H, hipStream_t st)
+           void* h_out, float* c_out, float* h_out_f32, int64_t B, int H, hipStream_t st, void* act_out = nullptr, int act_gates = 4,
+           void* h_next = nullptr, int64_t next_stride = 0, const float* keep_next = nullptr)
 {
     static int cus = 0;
     if (!cus) {
@@ -409,9 +453,14 @@ int launch(const void* x, const void* h_prev, const float* c_prev, const float* 
     int split = 1;                                        // aim for >= 2 workgroups per CU, split a power of two <= H/32
     while (split < H / NSLICE && row_blocks * split < int64_t(2) * cus) split *= 2;
     while ((H / NSLICE) % split) split /= 2;
-    hipLaunchKernelGGL((lstm_cell_mfma_dma_kernel<KX, KH>), dim3(unsigned(row_blocks), unsigned(split)), dim3(256), 0, st,
-                       (const uint16_t*)x, (const uint16_t*)h_prev, c_prev, keep, (const uint16_t*)W, bias, (uint16_t*)h_out, c_out,
-                       h_out_f32, B, H, split);
+    if (act_out || h_next)
+        hipLaunchKernelGGL((lstm_cell_mfma_dma_kernel<KX, KH, true>), dim3(unsigned(row_blocks), unsigned(split)), dim3(256), 0, st,
+                           (const uint16_t*)x, (const uint16_t*)h_prev, c_prev, keep, (const uint16_t*)W, bias, (uint16_t*)h_out, c_out,
+                           h_out_f32, B, H, split, (uint16_t*)act_out, act_gates, (uint16_t*)h_next, next_stride, keep_next);
+    else
+        hipLaunchKernelGGL((lstm_cell_mfma_dma_kernel<KX, KH, false>), dim3(unsigned(row_blocks), unsigned(split)), dim3(256), 0, st,
+                           (const uint16_t*)x, (const uint16_t*)h_prev, c_prev, keep, (const uint16_t*)W, bias, (uint16_t*)h_out, c_out,
+                           h_out_f32, B, H, split, (uint16_t*)nullptr, 4, (uint16_t*)nullptr, int64_t(0), (const float*)nullptr);
     return int(hipGetLastError());
 }
 
@@ -440,4 +489,26 @@ extern "C" int fdyn_lstm_cell_mfma(const void* x, int kx, const void* h_prev, in
     if (kx == 256 && kh == 0) return launch<256, 0>(x, h_prev, c_prev, keep, W, bias, h_out, c_out, h_out_f32, B, H, st);
     if (kx == 128 && kh == 128) return launch<128, 128>(x, h_prev, c_prev, keep, W, bias, h_out, c_out, h_out_f32, B, H, st);
     return FDYN_ERR_BAD_SIZE;      // supported (input, recurrent) widths: (128,256) (128,0) (256,0) (128,128)
+}
+
+// BPTT forward of the same cell: besides h' and c' the kernel leaves what the backward pass needs -- the activated gates
+// (bf16 [B][act_gates * H]; zero-state layers, kh = 0, use the three-gate layout (i, g, o) and take c_out = NULL) -- and packs
+// h' * keep_next into the recurrent columns of the next step's input row.  The [B, 4H] pre-activations never exist in HBM:
+// the un-fused training step wrote them from the GEMM and read them back in the point-wise kernel.
+extern "C" int fdyn_lstm_cell_mfma_train(const void* x, int kx, const void* h_prev, int kh, const float* c_prev, const float* keep,
+                                         const void* W, const float* bias, void* h_out, float* c_out, void* act_out,
+                                         void* h_next, int64_t next_stride, const float* keep_next, int64_t B, int H, void* stream)
+{
+    if (B < 0 || H <= 0 || H % NSLICE || (h_next && next_stride < H)) return FDYN_ERR_BAD_SIZE;
+    if (!x || !W || !bias || !h_out || !act_out) return FDYN_ERR_NULL;
+    if (kh > 0 && (!h_prev || !c_prev || !c_out)) return FDYN_ERR_NULL;
+    if (int64_t(32) * 4 * H * 2 > (int64_t(1) << 31) || int64_t(32) * next_stride * 2 > (int64_t(1) << 31)) return FDYN_ERR_BAD_SIZE;
+    if (B == 0) return FDYN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int ng = kh > 0 ? 4 : 3;
+    if (kx == 128 && kh == 256) return launch<128, 256>(x, h_prev, c_prev, keep, W, bias, h_out, c_out, nullptr, B, H, st, act_out, ng, h_next, next_stride, keep_next);
+    if (kx == 128 && kh == 0) return launch<128, 0>(x, h_prev, c_prev, keep, W, bias, h_out, c_out, nullptr, B, H, st, act_out, ng, h_next, next_stride, keep_next);
+    if (kx == 256 && kh == 0) return launch<256, 0>(x, h_prev, c_prev, keep, W, bias, h_out, c_out, nullptr, B, H, st, act_out, ng, h_next, next_stride, keep_next);
+    if (kx == 128 && kh == 128) return launch<128, 128>(x, h_prev, c_prev, keep, W, bias, h_out, c_out, nullptr, B, H, st, act_out, ng, h_next, next_stride, keep_next);
+    return FDYN_ERR_BAD_SIZE;
 }

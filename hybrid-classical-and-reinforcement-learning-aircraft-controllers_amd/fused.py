@@ -3,6 +3,7 @@
 `lstm_cell(gates, c_prev)` = the LSTM point-wise update; on a GPU tensor it is ONE HIP launch forward and one backward,
 on a CPU tensor (unit tests, gloo rehearsals) it is the same arithmetic in plain torch ops.
 """
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -163,6 +164,23 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], min_rows
     return torch.nn.functional.linear(x, w, b)
 
 
+# Which BPTT forwards take the fused MFMA cell (fdyn_lstm_cell_mfma_train).  Measured on MI355X at the bench's train workload
+# (65 536 envs, 16 steps, 2 x 2 slices; PPO iteration, 8 timed iterations each): "0" 56.6-56.9 ms, "fe" 55.9, "seq" 58.0,
+# "all" 56.9-57.1 -- the fused kernel moves its 1.5x larger output (activated gates, packed next input) at the ~2.5 TB/s its
+# 64-byte row segments reach, which is what hipBLASLt's GEMM + the 5.4 TB/s point-wise kernel take together; for the recurrent
+# steps, where the actor's and the critic's un-fused chains overlap in the graph, it loses.  Hence "fe".
+MFMA_TRAIN_DEFAULT = "fe"
+
+
+def _mfma_train_ok(t: torch.Tensor, kx: int, kh: int, H: int) -> bool:
+    """The BPTT forward takes the fused MFMA cell (csrc/lstm_mfma.hip, TRAIN) for the shapes that kernel is built for."""
+    mode = os.environ.get("FDYN_MFMA_TRAIN", MFMA_TRAIN_DEFAULT)        # "all", "seq" (recurrent cells), "fe" (zero-state layers), "0"
+    if mode not in ("all", "seq" if kh else "fe"):
+        return False
+    return (t.is_cuda and t.dtype == torch.bfloat16 and H % 32 == 0 and (kx, kh) in ((128, 256), (128, 0), (256, 0), (128, 128))
+            and (kh == 0 or kh == H))
+
+
 def _bsum_rows_per_block(rows: int, H: int) -> int:
     """Rows a block of the bias-summing backward kernels owns (0 = this H cannot keep one column per lane)."""
     hv = H // 8
@@ -199,16 +217,27 @@ class _ZeroStateLayerFn(torch.autograd.Function):
         assert bf16 or dt == torch.float32
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         M = x2.shape[0]
-        with torch.autocast("cuda", enabled=False):
-            w3 = torch.cat([w_ih[:H], w_ih[2 * H:]]).to(dt)                                   # rows of i, g, o
-            b = b_ih + b_hh
-            b3 = torch.cat([b[:H], b[2 * H:]]).to(dt)
-            gates = torch.addmm(b3, x2, w3.t())                                               # [M, 3H], bias in the epilogue
         need = any(ctx.needs_input_grad)
         h = torch.empty((M, H), dtype=dt, device=x.device)
-        # the activated gates overwrite the pre-activations in place
-        _lib.check(lib.fdyn_lstm_cell0_fwd(gates.data_ptr(), int(bf16), h.data_ptr(), gates.data_ptr() if need else None, M, H,
-                                           _lib.current_stream()), "lstm_cell0_fwd")
+        if need and _mfma_train_ok(x2, x2.shape[1], 0, H):
+            # GEMM + gate non-linearities + cell update in ONE MFMA kernel: the [M, 3H] pre-activations never exist in HBM
+            with torch.autocast("cuda", enabled=False):
+                w4 = w_ih.to(dt).contiguous()
+                w3 = torch.cat([w4[:H], w4[2 * H:]])                                          # rows of i, g, o (backward GEMMs)
+                b32 = (b_ih + b_hh).float().contiguous()
+            gates = torch.empty((M, 3 * H), dtype=dt, device=x.device)
+            _lib.check(lib.fdyn_lstm_cell_mfma_train(x2.data_ptr(), x2.shape[1], None, 0, None, None, w4.data_ptr(), b32.data_ptr(),
+                                                     h.data_ptr(), None, gates.data_ptr(), None, 0, None, M, H,
+                                                     _lib.current_stream()), "lstm_cell_mfma_train")
+        else:
+            with torch.autocast("cuda", enabled=False):
+                w3 = torch.cat([w_ih[:H], w_ih[2 * H:]]).to(dt)                               # rows of i, g, o
+                b = b_ih + b_hh
+                b3 = torch.cat([b[:H], b[2 * H:]]).to(dt)
+                gates = torch.addmm(b3, x2, w3.t())                                           # [M, 3H], bias in the epilogue
+            # the activated gates overwrite the pre-activations in place
+            _lib.check(lib.fdyn_lstm_cell0_fwd(gates.data_ptr(), int(bf16), h.data_ptr(), gates.data_ptr() if need else None, M, H,
+                                               _lib.current_stream()), "lstm_cell0_fwd")
         if need:
             ctx.save_for_backward(x2, w3, gates)
             ctx.H, ctx.xshape, ctx.dtypes = H, x.shape, (w_ih.dtype, b_ih.dtype, b_hh.dtype)
@@ -377,7 +406,24 @@ class _LSTMSequenceFn(torch.autograd.Function):
         c_all[0].copy_(c0)
         h_seq = torch.empty((T, G, B, H), dtype=dt, device=dev)
         st, R, esz = _lib.current_stream(), G * B, x_all.element_size()
-        for t in range(T):
+        if need and _mfma_train_ok(feats, kx, H, H):
+            # every step of every cell is ONE MFMA kernel (GEMM + gate non-linearities + cell update + the activated gates for
+            # the backward pass + the next step's recurrent input columns): no [B, 4H] pre-activations in HBM
+            wc, b32 = w.contiguous(), torch.stack([params[4 * g + 2] + params[4 * g + 3] for g in range(G)]).float().contiguous()
+            h0c = h0.to(dt).contiguous()
+            for t in range(T):
+                last = t == T - 1
+                for g in range(G):
+                    hp = h0c[g] if t == 0 else h_seq[t - 1, g]
+                    _lib.check(lib.fdyn_lstm_cell_mfma_train(
+                        feats[t].data_ptr(), kx, hp.data_ptr(), H, c_all[t, g].data_ptr(), keep[t].data_ptr(), wc[g].data_ptr(),
+                        b32[g].data_ptr(), h_seq[t, g].data_ptr(), c_all[t + 1, g].data_ptr(), act[t, g].data_ptr(),
+                        None if last else x_all[t + 1, g].data_ptr() + kx * esz, K, None if last else keep[t + 1].data_ptr(),
+                        B, H, st), "lstm_cell_mfma_train")
+            T_done = T
+        else:
+            T_done = 0
+        for t in range(T_done, T):
             gates = torch.bmm(x_all[t], wT)                                  # [G, B, 4H]; the bias is added in the cell kernel
             last = t == T - 1
             _lib.check(lib.fdyn_lstm_seq_fwd(gates.data_ptr(), int(bf16), c_all[t].data_ptr(), keep_rows[t].data_ptr(),

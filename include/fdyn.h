@@ -225,6 +225,14 @@ int fdyn_ppo_loss(const float* mean, const float* actions, const float* log_std,
 int fdyn_lstm_cell_mfma(const void* x, int kx, const void* h_prev, int kh, const float* c_prev, const float* keep,
                         const void* W, const float* bias, void* h_out, float* c_out, float* h_out_f32,
                         int64_t B, int H, void* stream);
+/* BPTT forward of the same cell (csrc/lstm_mfma.hip, TRAIN instantiation): besides h_out / c_out it stores the ACTIVATED gates
+ * act_out (bf16; kh > 0: [B][4H] = sigmoid(i), sigmoid(f), tanh(g), sigmoid(o); kh = 0, the zero-state layers of the features
+ * extractor: [B][3H] = (i, g, o), c_out may be NULL) for fdyn_lstm_seq_bwd / fdyn_lstm_cell0_bwd, and -- h_next != NULL --
+ * h' * keep_next into rows of stride next_stride (the recurrent columns of the next step's [x | h] row, which the weight-gradient
+ * GEMM reads).  Replaces the training step's GEMM -> [B][4H] pre-activations in HBM -> fdyn_lstm_seq_fwd round trip. */
+int fdyn_lstm_cell_mfma_train(const void* x, int kx, const void* h_prev, int kh, const float* c_prev, const float* keep,
+                              const void* W, const float* bias, void* h_out, float* c_out, void* act_out,
+                              void* h_next, int64_t next_stride, const float* keep_next, int64_t B, int H, void* stream);
 /* The policy's features extractor as ONE kernel (csrc/policy_fe64.hip; learned_controllers/networks/lstm_policy.py:13-97):
  * obs [B][18] fp32 -> Linear(18,128)+ReLU -> two zero-state LSTM layers (128->256->256) -> Linear(256,128)+ReLU -> feats
  * [B][128] bf16, activations in registers between the layers.  weight_image: the four weight matrices as bf16 in the

@@ -173,6 +173,52 @@ def test_lstm_mfma_cell_matches_plain_torch_fp32(B, kx, kh, with_h32):
     assert (h_out.float() - h_ref).abs().max() < 1e-2
 
 
+@pytest.mark.parametrize("B", [777, 4096, 32768])
+@pytest.mark.parametrize("kx,kh", [(128, 256), (128, 0), (256, 0)])
+def test_lstm_mfma_train_cell_matches_plain_torch_fp32(B, kx, kh):
+    """The BPTT-forward instantiation of the MFMA cell (fdyn_lstm_cell_mfma_train) vs plain PyTorch fp32 on the same
+    bf16-rounded inputs: h', c', the activated gates it leaves for the backward pass (four-gate layout for the recurrent
+    cell, three-gate (i, g, o) for a zero-state layer) and h' * keep_next packed into rows of a wider stride."""
+    from hcrl_amd import _lib
+    torch.manual_seed(B + kx + kh + 1)
+    H, lib = 256, _lib.load()
+    x = (torch.randn(B, kx, device="cuda") * 0.7).bfloat16()
+    W = (torch.randn(4 * H, kx + kh, device="cuda") * 0.08).bfloat16()
+    bias = torch.randn(4 * H, device="cuda") * 0.3
+    if kh:
+        h = (torch.randn(B, kh, device="cuda") * 0.5).bfloat16()
+        c = torch.randn(B, H, device="cuda")
+        keep = (torch.rand(B, device="cuda") > 0.25).float()
+        xin = torch.cat([x.float(), h.float() * keep[:, None]], 1)
+        c_eff = c * keep[:, None]
+    else:
+        h = c = keep = None
+        xin, c_eff = x.float(), None
+    keep_next = (torch.rand(B, device="cuda") > 0.25).float()
+    gates = xin @ W.float().t() + bias
+    i, f, g, o = gates.chunk(4, 1)
+    si, sf, tg, so = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)
+    c_ref = si * tg + (sf * c_eff if kh else 0)
+    h_ref = so * torch.tanh(c_ref)
+    act_ref = torch.cat([si, sf, tg, so] if kh else [si, tg, so], 1)
+    ng, K2 = (4 if kh else 3), kx + H + 8
+    h_out = torch.empty(B, H, dtype=torch.bfloat16, device="cuda")
+    c_out = torch.empty(B, H, device="cuda") if kh else None
+    act = torch.full((B, ng * H), 7.0, dtype=torch.bfloat16, device="cuda")
+    nxt = torch.full((B, K2), 9.0, dtype=torch.bfloat16, device="cuda")          # h' * keep_next goes to columns kx .. kx + H
+    _lib.check(lib.fdyn_lstm_cell_mfma_train(x.data_ptr(), kx, _lib.ptr(h), kh, _lib.ptr(c), _lib.ptr(keep), W.data_ptr(),
+                                             bias.data_ptr(), h_out.data_ptr(), _lib.ptr(c_out), act.data_ptr(),
+                                             nxt.data_ptr() + kx * 2, K2, keep_next.data_ptr(), B, H, _lib.current_stream()),
+               "lstm_cell_mfma_train")
+    torch.cuda.synchronize()
+    if kh:
+        assert (c_out - c_ref).abs().max() < 2e-3
+    assert (h_out.float() - h_ref).abs().max() < 1e-2
+    assert (act.float() - act_ref).abs().max() < 1e-2, float((act.float() - act_ref).abs().max())
+    assert (nxt[:, kx:kx + H].float() - h_out.float() * keep_next[:, None]).abs().max() == 0.0
+    assert bool((nxt[:, :kx] == 9.0).all()) and bool((nxt[:, kx + H:] == 9.0).all())      # nothing outside its columns
+
+
 def test_fused_rollout_step_matches_unfused_bf16_path():
     torch.manual_seed(0)
     p = RateLSTMPolicy(compute_dtype=torch.bfloat16).cuda()
@@ -399,9 +445,19 @@ def test_deferred_splitk_weight_gradients_match_plain_autograd(dtype, tol):
     pol.group_cells_max_batch = 0
     seq1 = grads(True, 8192, sequence=True)                   # one node per cell (the large-slice path)
     pol.group_cells_max_batch = 8192
-    assert set(plain) == set(fast) == set(seq) == set(seq1)
+    # every BPTT forward through the fused MFMA cell (fdyn_lstm_cell_mfma_train; bf16 only -- the default uses it for the
+    # features extractor's layers alone), and none at all
+    mode = fused.MFMA_TRAIN_DEFAULT
+    try:
+        fused.MFMA_TRAIN_DEFAULT = "all"
+        seq_mfma = grads(True, 8192, sequence=True)
+        fused.MFMA_TRAIN_DEFAULT = "0"
+        seq_plain_fwd = grads(True, 8192, sequence=True)
+    finally:
+        fused.MFMA_TRAIN_DEFAULT = mode
+    assert set(plain) == set(fast) == set(seq) == set(seq1) == set(seq_mfma) == set(seq_plain_fwd)
     for n in plain:
-        for other in (fast, seq, seq1):                       # seq: the whole recurrence as one autograd node
+        for other in (fast, seq, seq1, seq_mfma, seq_plain_fwd):      # seq: the whole recurrence as one autograd node
             a, b = plain[n], other[n]
             err = float((a - b).norm() / (a.norm() + 1e-12))
             assert err < tol, (n, err, other is seq, other is seq1)
