@@ -31,6 +31,7 @@ template <> struct M<double> {
     static FD_DEV double sqrt(double x) { return ::sqrt(x); }
     static FD_DEV double exp(double x) { return ::exp(x); }
     static FD_DEV double abs(double x) { return ::fabs(x); }
+    static FD_DEV double copysign(double a, double y) { return __builtin_copysign(a, y); }
     static FD_DEV double rint(double x) { return ::rint(x); }
     static FD_DEV double fmod(double x, double y) { return ::fmod(x, y); }
     static FD_DEV bool finite(double x) { return ::isfinite(x); }
@@ -113,6 +114,18 @@ FD_DEV float asin_wide(float x)
     p = __builtin_fmaf(z, p, 1.6666238010e-01f);
     return __builtin_fmaf(p * z, x, x);
 }
+// the same polynomial on (t, z = t^2) given separately (the caller's z may be cheaper or more accurate than t * t)
+FD_DEV float asin_wide_t(float t, float z)
+{
+    float p = __builtin_fmaf(z, 2.1202674508e-01f, -3.1944271922e-01f);
+    p = __builtin_fmaf(z, p, 2.6334178448e-01f);
+    p = __builtin_fmaf(z, p, -7.6388612390e-02f);
+    p = __builtin_fmaf(z, p, 5.3024884313e-02f);
+    p = __builtin_fmaf(z, p, 4.1755288839e-02f);
+    p = __builtin_fmaf(z, p, 7.5183674693e-02f);
+    p = __builtin_fmaf(z, p, 1.6666238010e-01f);
+    return __builtin_fmaf(p * z, t, t);
+}
 FD_DEV float atan_pos(float a)
 {   // atan for a >= 0 (Cephes atanf: two range reductions + degree-4 polynomial in a^2), branch-free
     const bool big = a > 2.414213562373095f, mid = a > 0.4142135623730950f;
@@ -181,6 +194,7 @@ template <> struct M<float> {
     static FD_DEV float sqrt(float x) { return fast::sqrt(x); }
     static FD_DEV float exp(float x) { return __expf(x); }
     static FD_DEV float abs(float x) { return __builtin_fabsf(x); }
+    static FD_DEV float copysign(float a, float y) { return __builtin_copysignf(a, y); }
     static FD_DEV float rint(float x) { return __builtin_rintf(x); }
     static FD_DEV float fmod(float x, float y) { return ::fmodf(x, y); }
     static FD_DEV bool finite(float x) { return __builtin_isfinite(x); }
@@ -439,6 +453,18 @@ FD_DEV float trig_rotate(const Trig& t0, float dphi, float dth, float dpsi, Trig
 }
 
 #define FD_UNLIKELY(c) __builtin_expect(!!(c), 0)
+#ifdef FD_PHASE_STAMPS
+// timing experiment only: how often wave 0 of a workgroup enters the rare blocks ([0] wave entries, [1] lane entries of the
+// dynamics block; [2], [3] the same for the post-step fix-up; [4] lanes rebuilding the trigonometry)
+__device__ unsigned fdyn_dbg_cnt[4096 * 8];
+#define FD_DBG_COUNT(SLOT) if (threadIdx.x < 64) { const unsigned long long m_ = __ballot(1); \
+    if (int(threadIdx.x) == __ffsll((long long)m_) - 1) atomicAdd(&fdyn_dbg_cnt[blockIdx.x * 8 + (SLOT)], 1u); \
+    atomicAdd(&fdyn_dbg_cnt[blockIdx.x * 8 + (SLOT) + 1], 1u); }
+#define FD_DBG_COUNT1(SLOT) if (threadIdx.x < 64) atomicAdd(&fdyn_dbg_cnt[blockIdx.x * 8 + (SLOT)], 1u);
+#else
+#define FD_DBG_COUNT(SLOT)
+#define FD_DBG_COUNT1(SLOT)
+#endif
 
 // x: the 12 state words (x[0..2] unread; x[6], x[8] read only when the trigonometry has to be rebuilt); tg is updated in
 // place when it is rebuilt, so a carried Trig stays repaired.
@@ -467,20 +493,35 @@ FD_DEV void dynamics_fast(const Params<float>& P, const Controls<float>& C, cons
     const float sin_alpha = a_in ? w * inv_h : __builtin_copysignf(P.sin_max_alpha, w);
     const float cos_alpha = a_in ? us * inv_h : P.cos_max_alpha;
 
-    // ---- side-slip :376, polynomial up to |v| / V = 0.75
-    float beta = fast::asin_wide(v * inv_V);
+    // ---- side-slip :376, ONE polynomial, branch-free over the whole range.  Up to |v| / V = 0.75 its argument is v / V; beyond
+    // it asin = pi/2 - 2 asin(sqrt((1 - |x|) / 2)) with 1 - |v|/V = (u^2 + w^2) / (V (V + |v|)) -- no cancellation: asin is
+    // ill-conditioned at +-1, a tumbling aircraft at the rate clamp flies sideways with |v| / V = 1 - 2e-8, which fp32 rounds to
+    // 1 and beta is off by 3e-4 rad (measured as THE source of mixed-precision outliers over 4096 aircraft).  The second form
+    // used to live in the rare block below: but sideways flight is STICKY -- in the steady state of the bench's random-action
+    // fleet every second wave holds an aircraft beyond 48 deg of side-slip, ran the rare block on all 80 evaluations of an env
+    // step (113 k cycles for the RK4 phase against 72 k, scratch/phase_stamps.py) and the launch waited for those waves.
+    const float av = __builtin_fabsf(v);
+    const bool b_in = av <= FD_ASIN_WIDE_LIMIT * Vs;
+    const float vv_rest = airspeed >= P.min_airspeed ? uw2 : __builtin_fmaxf(__builtin_fmaf(Vs, Vs, -(v * v)), 0.0f);   // V^2 - v^2 (V clamped: :364)
+    const float half_om = 0.5f * (vv_rest * fast::rcp(Vs * (Vs + av)));                     // (1 - |v| / V) / 2, <= 0.125 where it is used
+    const float xb = v * inv_V;
+    const float b_t = b_in ? xb : fast::sqrt(half_om);
+    const float b_r = fast::asin_wide_t(b_t, b_in ? xb * xb : half_om);
+    const float beta = b_in ? b_r : __builtin_copysignf(__builtin_fmaf(-2.0f, b_r, 1.5707963267948966f), v);
 
     // ---- clamped pitch for the Euler rates :463: sin / cos of clip(theta) are the carried ones or those of +-max_pitch
     const bool th_in = __builtin_fabsf(theta) <= P.max_pitch;
     float sth_e = th_in ? tg.sth : __builtin_copysignf(P.sin_max_pitch, theta);
     float cth_e = th_in ? tg.cth : P.cos_max_pitch;
 
-    // ---- the rare block (2-5 % of waves under random actions): side-slip beyond 48 deg, an Euler-angle increment too large
-    // for the rotation series, or an aircraft type whose alpha limit lies beyond the polynomial
-    const bool ordinary = (__builtin_fabsf(v) <= FD_ASIN_WIDE_LIMIT * Vs) & (dmax <= 0.125f) & (P.alpha_needs_atan2 == 0.0f);
+    // ---- the rare block: an Euler-angle increment too large for the rotation series (after a wrap / pitch clamp, or 10 ms steps
+    // of a tumbling aircraft), or an aircraft type whose alpha limit lies beyond the polynomial -- transient or absent
+    const bool ordinary = (dmax <= 0.125f) & (P.alpha_needs_atan2 == 0.0f);
     float alpha_r = alpha, sin_alpha_r = sin_alpha, cos_alpha_r = cos_alpha;
     if (FD_UNLIKELY(!ordinary)) {
+        FD_DBG_COUNT(0)
         if (!(dmax <= 0.125f)) {
+            FD_DBG_COUNT1(4)
             tg = trig_of(x[6], theta, x[8]);
             sth_e = th_in ? tg.sth : sth_e; cth_e = th_in ? tg.cth : cth_e;
         }
@@ -490,16 +531,6 @@ FD_DEV void dynamics_fast(const Params<float>& P, const Controls<float>& C, cons
             sin_alpha_r = hi ? P.sin_max_alpha : (lo ? -P.sin_max_alpha : w * inv_h);
             cos_alpha_r = (hi || lo) ? P.cos_max_alpha : us * inv_h;
             alpha_r = clipf(a_raw, -P.max_alpha, P.max_alpha);
-        }
-        // asin is ill-conditioned at +-1 (sideways flight: a tumbling aircraft at the rate clamp has |v| / V = 1 - 2e-8,
-        // which fp32 rounds to 1 and beta is off by 3e-4 rad -- measured as THE source of mixed-precision outliers over 4096
-        // aircraft): asin = pi/2 - 2 asin(sqrt((1 - |x|) / 2)) with 1 - |v|/V = (u^2 + w^2) / (V (V + |v|)), no cancellation
-        const float xb = clipf(v * inv_V, -1.0f, 1.0f);
-        if (__builtin_fabsf(xb) > FD_ASIN_WIDE_LIMIT) {
-            const float av = __builtin_fabsf(v);
-            const float one_minus = (airspeed >= P.min_airspeed) ? uw2 * fast::rcp(Vs * (Vs + av))
-                                                                 : __builtin_fmaxf(Vs - av, 0.0f) * inv_V;
-            beta = __builtin_copysignf(fast::asin_from_one_minus(one_minus), xb);
         }
     }
     const float sphi = tg.sphi, cphi = tg.cphi, cpsi = tg.cpsi, spsi = tg.spsi, sth = tg.sth, cth = tg.cth;
@@ -643,22 +674,55 @@ FD_DEV void rk4_fast_step(const Params<float>& P, const Limits<S>& Lm, const Con
     dynamics_fast(P, C, xt, tt, dm, k);                                  // k4
     T inc[FD_NX];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) { inc[i] = dt6 * (acc[i] + k[i]); x[i] += S(inc[i]); f.x0[i] = T(x[i]); }
+    for (int i = 0; i < 12; ++i) {
+        inc[i] = dt6 * (acc[i] + k[i]);
+        x[i] += S(inc[i]);
+        // the body-rate clamp (:273) sits in the straight-line path, as a select in the storage type: it is the STICKY clamp -- an
+        // aircraft tumbling against it trips it on every sub-step, and behind the wave-level branch below it cost the wave
+        // holding that aircraft 20 fix-ups per env step (at one wave per SIMD the launch lasts as long as its slowest wave)
+        if (i >= 9) x[i] = M<S>::abs(x[i]) > Lm.max_rate ? M<S>::copysign(Lm.max_rate, x[i]) : x[i];
+        f.x0[i] = T(x[i]);
+    }
     f.d0 = trig_rotate(f.t0, inc[6], inc[7], inc[8], f.t0);
     // one predicate for every clamp / wrap / guard of :256-291, evaluated on the fp32 copy
     T sum = f.x0[0];
 #pragma unroll
     for (int i = 1; i < 12; ++i) sum += f.x0[i];
     const T vmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(f.x0[3]), __builtin_fabsf(f.x0[4])), __builtin_fabsf(f.x0[5]));
-    const T rmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(f.x0[9]), __builtin_fabsf(f.x0[10])), __builtin_fabsf(f.x0[11]));
     const T amax = __builtin_fmaxf(__builtin_fabsf(f.x0[6]), __builtin_fabsf(f.x0[8]));
-    const bool fix = !(vmax <= T(Lm.max_vel)) | !(rmax <= T(Lm.max_rate)) | !(__builtin_fabsf(f.x0[7]) <= T(Lm.max_pitch)) |
-                     !(amax <= T(FD_PI)) | (f.x0[2] > T(0)) | !M<T>::finite(sum);
-    if (FD_UNLIKELY(fix)) {
-        post_step<S, T>(Lm, x);
+    // Two classes.  `lim`: the velocity clamp, ground contact and the roll / yaw re-wraps (:262, :266, :270, :276-283) leave
+    // sin / cos of the angles alone (a wrap moves the angle by 2 pi), so the carried trigonometry stays valid and only the
+    // touched words are refreshed -- in the steady state of the bench's fleet some aircraft of every wave wraps its yaw once
+    // per env step.  `ang`: the pitch clamp and non-finite values; these take the full post_step and ask for the rebuild.  (Round 2's first form put all of post_step + a full
+    // sincos rebuild behind one predicate that included the rate clamp: a wave holding one aircraft at that clamp ran 20
+    // fix-ups + 19 rebuilds per env step, 100-111 k cycles for the RK4 phase against 71.6 k for an undisturbed wave --
+    // scratch/phase_stamps.py, shader-clock stamps -- and the launch waited for it.)
+    const bool lim = !(vmax <= T(Lm.max_vel)) | (f.x0[2] > T(0)) | !(amax <= T(FD_PI));
+    const bool ang = !(__builtin_fabsf(f.x0[7]) <= T(Lm.max_pitch)) | !M<T>::finite(sum);
+    if (FD_UNLIKELY(lim | ang)) {
+        FD_DBG_COUNT(2)
+#ifdef FD_PHASE_STAMPS
+        if (!(vmax <= T(Lm.max_vel))) { FD_DBG_COUNT1(5) }
+        if (f.x0[2] > T(0)) { FD_DBG_COUNT1(7) }
+#endif
+        if (ang) {
+            post_step<S, T>(Lm, x);
 #pragma unroll
-        for (int i = 0; i < 12; ++i) f.x0[i] = T(x[i]);
-        f.d0 = T(1);                                             // the next user rebuilds the trigonometry in full
+            for (int i = 0; i < 12; ++i) f.x0[i] = T(x[i]);
+            f.d0 = T(1);                                         // the next user rebuilds the trigonometry in full
+        } else {
+#pragma unroll
+            for (int i = 3; i < 6; ++i) x[i] = clipv(x[i], -Lm.max_vel, Lm.max_vel);          // :262
+            x[6] = wrap_state_angle<S, T>(x[6]);                                               // :266
+            x[8] = wrap_state_angle<S, T>(x[8]);                                               // :270
+            if (-x[2] < S(0)) {                                                                // :276-283 ground clamp
+                x[2] = S(0);
+                x[5] = x[5] > S(0) ? x[5] : S(0);
+            }
+            f.x0[2] = T(x[2]); f.x0[6] = T(x[6]); f.x0[8] = T(x[8]);
+#pragma unroll
+            for (int i = 3; i < 6; ++i) f.x0[i] = T(x[i]);
+        }
     }
 }
 

@@ -582,6 +582,31 @@ rate_env_reset_kernel(S* __restrict__ xs, E* __restrict__ es, int32_t* __restric
     store_obs_tile(s_tile[wave], o, lane, obs_out, lm.wave_first, n);
 }
 
+#ifdef FD_PHASE_STAMPS
+// timing experiment (scratch/phase_stamps.py; never in the shipped build): shader-clock stamps of wave 0 of every workgroup at
+// five points of the env step -> where the 22 % of wave cycles that rocprofv3 reports as waiting are spent
+__device__ unsigned long long fdyn_stamps[4096 * 8];
+#define FD_STAMP(K) if (threadIdx.x == 0 && blockIdx.x < 4096) fdyn_stamps[blockIdx.x * 8 + (K)] = __builtin_readcyclecounter();
+#define FD_STAMP_REAL(K) if (threadIdx.x == 0 && blockIdx.x < 4096) fdyn_stamps[blockIdx.x * 8 + (K)] = wall_clock64();   /* 100 MHz, chip-wide */
+extern "C" int fdyn_debug_read_stamps(unsigned long long* out, int count)
+{
+    return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(fdyn_stamps), sizeof(unsigned long long) * size_t(count)));
+}
+extern "C" int fdyn_debug_read_counts(unsigned* out, int count, int clear)
+{
+    int rc = int(hipMemcpyFromSymbol(out, HIP_SYMBOL(fdyn_dbg_cnt), sizeof(unsigned) * size_t(count)));
+    if (clear && rc == 0) {
+        void* p = nullptr;
+        rc = int(hipGetSymbolAddress(&p, HIP_SYMBOL(fdyn_dbg_cnt)));
+        if (rc == 0) rc = int(hipMemset(p, 0, sizeof(unsigned) * 4096 * 8));
+    }
+    return rc;
+}
+#else
+#define FD_STAMP(K)
+#define FD_STAMP_REAL(K)
+#endif
+
 // OCC2: cap the registers at 256 so that two waves fit per SIMD.  At exactly one wave per SIMD (65 536 envs on 256 CUs) the
 // uncapped allocation (258 VGPRs) is 4 % faster; past that the second wave hides the first one's issue gaps
 // (1 Mi envs: 1.16e9 -> 1.56e9 env-steps/s).  The launcher picks by batch size; the arithmetic is the same.
@@ -604,6 +629,8 @@ rate_env_step_kernel(S* __restrict__ xs, typename EnvOf<S, T>::type* __restrict_
     __shared__ float s_tile[FD_BLOCK / FD_WAVE][FD_WAVE * (FD_OBS_DIM + 1)];
     __shared__ float s_pid_cfg[3 * FD_NPC];
     __shared__ S s_consts[FD_NC];
+    FD_STAMP(0)
+    FD_STAMP_REAL(7)
     const LaneMap lm = lane_map(n);
     const int64_t i = lm.i;
     const int lane = lm.lane, wave = threadIdx.x / FD_WAVE;
@@ -697,7 +724,12 @@ rate_env_step_kernel(S* __restrict__ xs, typename EnvOf<S, T>::type* __restrict_
         Controls<T> C;
         C.set(P, a[1], a[0], a[2], a[3]);                                         // action = [ail, elev, rud, thr]
         const S dt_sub = ec.dt / S(ec.n_sub);
+#ifdef FD_PHASE_STAMPS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+        FD_STAMP(1)
         rk4_substeps<S, T>(P, Lm, C, x, dt_sub, ec.n_sub);
+        FD_STAMP(2)
         if constexpr (sizeof(E) == sizeof(S)) e.time += E(ec.dt);                 // :241-242 (the reference's accumulated sum)
         else e.time = E(S(step + 1) * ec.dt);                                     // fp32 env words: exact product, not an fp32 running sum
         step += 1;
@@ -760,6 +792,7 @@ rate_env_step_kernel(S* __restrict__ xs, typename EnvOf<S, T>::type* __restrict_
         truncated[i] = trunc ? 1 : 0;
     }
 
+    FD_STAMP(3)
     // ---- K4: episode-done compaction -- wave ballot + mbcnt prefix, one atomic per wave ---------------------
     // The returning atomic is ISSUED here and its result consumed only after the auto-reset below: the reset work of the
     // finished lanes (Philox draws / pool reads, first observation) covers the atomic's round trip.
@@ -812,7 +845,13 @@ rate_env_step_kernel(S* __restrict__ xs, typename EnvOf<S, T>::type* __restrict_
             for (int k = 0; k < FD_OBS_DIM; ++k) ev_flt[slot * FD_EV_NF + 1 + k] = o_term[k];
         }
     }
+    FD_STAMP(4)
     store_obs_tile(s_tile[wave], o, lane, obs_out, lm.wave_first, n);
+    FD_STAMP(5)
+#ifdef FD_PHASE_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    FD_STAMP_REAL(6)
 }
 
 // =========================================================================================================
