@@ -42,6 +42,16 @@ template <> struct M<double> {
 // ~1 ulp (<= 1.2e-7 abs on sin/cos), i.e. the same order as the fp32 rounding the variant already accepts.
 namespace fast {
 FD_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }          // v_rcp_f32, 1 ulp
+// max of two values that are numbers: ONE v_max_f32.  __builtin_fmaxf is llvm.maxnum, which in IEEE mode first canonicalises
+// every operand the compiler cannot prove quiet (v_max_f32 x, x -- two wasted instructions per call on a sqrt result and a
+// staged parameter), and at one wave per SIMD an instruction is 5 cycles whatever it does.
+// (v_med3_f32 with +inf as the third operand; NOT inline assembly: the compiler inserts the wait state a VALU instruction needs
+// after the transcendental that produced its operand only for instructions it can see -- a v_max in an asm block right after
+// v_sqrt read the old register contents.)
+FD_DEV float max_nc(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
+// keep a value out of the compiler's if-conversion heuristics: computed here, unconditionally (a select whose expensive arm
+// every lane needs anyway must not become a divergent branch: saveexec / xor / andn2 / cbranch + hazard nops per use)
+FD_DEV float pinned(float x) { asm volatile("" : "+v"(x)); return x; }
 FD_DEV float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }        // v_sqrt_f32, 1 ulp
 FD_DEV float rsq(float x) { return __builtin_amdgcn_rsqf(x); }          // v_rsq_f32, 1 ulp
 FD_DEV void sincos(float x, float& s, float& c)
@@ -477,7 +487,7 @@ FD_DEV void dynamics_fast(const Params<float>& P, const Controls<float>& C, cons
     const float uw2 = __builtin_fmaf(u, u, w * w);
     const float V2 = __builtin_fmaf(v, v, uw2);
     const float airspeed = fast::sqrt(V2);                                                  // :363
-    const float Vs = __builtin_fmaxf(airspeed, P.min_airspeed);                             // :364
+    const float Vs = fast::max_nc(airspeed, P.min_airspeed);                                // :364
     const float inv_V = fast::rcp(Vs);
 
     // ---- angle of attack :368-370, branch-free.  alpha only matters inside +-max_alpha: |w| <= tan(max_alpha) u_safe (which
@@ -485,11 +495,13 @@ FD_DEV void dynamics_fast(const Params<float>& P, const Controls<float>& C, cons
     // polynomial; otherwise atan2(w, u_safe) lies beyond the limit on the side of sign(w) and clips to copysign(max_alpha, w)
     // (u_safe < 0, w = +-0 included: atan2 = +-pi).  sin / cos of the UNCLIPPED alpha are w/h and u_safe/h.
     const float au = __builtin_fabsf(u);
-    const float us = au > 1e-6f ? __builtin_copysignf(__builtin_fmaxf(au, P.min_u), u) : P.min_u;
+    const float au_min = fast::max_nc(au, P.min_u);
+    const float us = au > 1e-6f ? __builtin_copysignf(au_min, u) : P.min_u;
     const float inv_h = fast::rsq(__builtin_fmaf(us, us, w * w));                           // |u_safe| >= min_u > 0
     const float t_alpha = w * fast::rcp(us);
     const bool a_in = __builtin_fabsf(w) <= P.tan_alpha_fast * us;
-    const float alpha = a_in ? fast::atan_wide(t_alpha) : __builtin_copysignf(P.max_alpha, w);
+    const float alpha_poly = fast::pinned(fast::atan_wide(t_alpha));
+    const float alpha = a_in ? alpha_poly : __builtin_copysignf(P.max_alpha, w);
     const float sin_alpha = a_in ? w * inv_h : __builtin_copysignf(P.sin_max_alpha, w);
     const float cos_alpha = a_in ? us * inv_h : P.cos_max_alpha;
 
