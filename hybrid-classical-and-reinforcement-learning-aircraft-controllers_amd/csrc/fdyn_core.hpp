@@ -478,6 +478,13 @@ __device__ unsigned fdyn_dbg_cnt[4096 * 8];
 
 // x: the 12 state words (x[0..2] unread; x[6], x[8] read only when the trigonometry has to be rebuilt); tg is updated in
 // place when it is rebuilt, so a carried Trig stays repaired.
+// STRAIGHT: where the STICKY special cases live.  true (launches of at most one wave per SIMD, where the launch lasts as long
+// as its slowest wave): in the straight-line path, as selects -- every wave pays ~10 % more instructions, none pays a
+// wave-level block on every evaluation.  false (two waves per SIMD, the register-capped env build for batches beyond 65 536:
+// throughput-bound, a slow wave's issue gaps are filled by its neighbour): behind the wave-level branches -- measured at 1 Mi
+// envs 2.41e9 env-steps/s against 2.25e9 with the straight form.  The arithmetic is the same expression for expression: the
+// two forms are bit-equal (tests/test_gpu_parity_scale.py compares the two env builds).
+template <bool STRAIGHT = true>
 FD_DEV void dynamics_fast(const Params<float>& P, const Controls<float>& C, const float (&x)[FD_NX], Trig& tg, float dmax,
                           float (&xd)[FD_NX])
 {
@@ -514,12 +521,23 @@ FD_DEV void dynamics_fast(const Params<float>& P, const Controls<float>& C, cons
     // step (113 k cycles for the RK4 phase against 72 k, scratch/phase_stamps.py) and the launch waited for those waves.
     const float av = __builtin_fabsf(v);
     const bool b_in = av <= FD_ASIN_WIDE_LIMIT * Vs;
-    const float vv_rest = airspeed >= P.min_airspeed ? uw2 : __builtin_fmaxf(__builtin_fmaf(Vs, Vs, -(v * v)), 0.0f);   // V^2 - v^2 (V clamped: :364)
-    const float half_om = 0.5f * (vv_rest * fast::rcp(Vs * (Vs + av)));                     // (1 - |v| / V) / 2, <= 0.125 where it is used
     const float xb = v * inv_V;
-    const float b_t = b_in ? xb : fast::sqrt(half_om);
-    const float b_r = fast::asin_wide_t(b_t, b_in ? xb * xb : half_om);
-    const float beta = b_in ? b_r : __builtin_copysignf(__builtin_fmaf(-2.0f, b_r, 1.5707963267948966f), v);
+    auto beta_tail = [&]() {                                 // |v| / V beyond 0.75
+        const float vv_rest = airspeed >= P.min_airspeed ? uw2 : __builtin_fmaxf(__builtin_fmaf(Vs, Vs, -(v * v)), 0.0f);   // V^2 - v^2 (V clamped: :364)
+        const float half_om = 0.5f * (vv_rest * fast::rcp(Vs * (Vs + av)));                 // (1 - |v| / V) / 2 <= 0.125
+        const float b_r = fast::asin_wide_t(fast::sqrt(half_om), half_om);
+        return __builtin_copysignf(__builtin_fmaf(-2.0f, b_r, 1.5707963267948966f), v);
+    };
+    float beta;
+    if constexpr (STRAIGHT) {
+        const float vv_rest = airspeed >= P.min_airspeed ? uw2 : __builtin_fmaxf(__builtin_fmaf(Vs, Vs, -(v * v)), 0.0f);
+        const float half_om = 0.5f * (vv_rest * fast::rcp(Vs * (Vs + av)));
+        const float b_t = b_in ? xb : fast::sqrt(half_om);
+        const float b_r = fast::asin_wide_t(b_t, b_in ? xb * xb : half_om);
+        beta = b_in ? b_r : __builtin_copysignf(__builtin_fmaf(-2.0f, b_r, 1.5707963267948966f), v);
+    } else {
+        beta = fast::asin_wide_t(xb, xb * xb);              // the tail is fixed up in the rare block below
+    }
 
     // ---- clamped pitch for the Euler rates :463: sin / cos of clip(theta) are the carried ones or those of +-max_pitch
     const bool th_in = __builtin_fabsf(theta) <= P.max_pitch;
@@ -528,7 +546,7 @@ FD_DEV void dynamics_fast(const Params<float>& P, const Controls<float>& C, cons
 
     // ---- the rare block: an Euler-angle increment too large for the rotation series (after a wrap / pitch clamp, or 10 ms steps
     // of a tumbling aircraft), or an aircraft type whose alpha limit lies beyond the polynomial -- transient or absent
-    const bool ordinary = (dmax <= 0.125f) & (P.alpha_needs_atan2 == 0.0f);
+    const bool ordinary = (dmax <= 0.125f) & (P.alpha_needs_atan2 == 0.0f) & (STRAIGHT | b_in);
     float alpha_r = alpha, sin_alpha_r = sin_alpha, cos_alpha_r = cos_alpha;
     if (FD_UNLIKELY(!ordinary)) {
         FD_DBG_COUNT(0)
@@ -543,6 +561,9 @@ FD_DEV void dynamics_fast(const Params<float>& P, const Controls<float>& C, cons
             sin_alpha_r = hi ? P.sin_max_alpha : (lo ? -P.sin_max_alpha : w * inv_h);
             cos_alpha_r = (hi || lo) ? P.cos_max_alpha : us * inv_h;
             alpha_r = clipf(a_raw, -P.max_alpha, P.max_alpha);
+        }
+        if constexpr (!STRAIGHT) {
+            if (!b_in) beta = beta_tail();
         }
     }
     const float sphi = tg.sphi, cphi = tg.cphi, cpsi = tg.cpsi, spsi = tg.spsi, sth = tg.sth, cth = tg.cth;
@@ -656,7 +677,7 @@ struct FastRK {
 // the state; the storage type S sees ONE add per word per step (x += S(dt/6 * sum)) -- that add is what keeps the "mixed"
 // variant inside the 1e-4 gate.  The clamps / wraps of :256-291 are tested on the fp32 copy with one combined predicate and
 // the (rare) fix-up runs under a wave-level branch.
-template <typename S>
+template <typename S, bool STRAIGHT = true>
 FD_DEV void rk4_fast_step(const Params<float>& P, const Limits<S>& Lm, const Controls<float>& C, S (&x)[FD_NX], FastRK& f,
                           float hdt, float fdt, float dt6)
 {
@@ -665,34 +686,37 @@ FD_DEV void rk4_fast_step(const Params<float>& P, const Limits<S>& Lm, const Con
     // angles (for the rare full rebuild and the +-85 deg guard) and rates; the trigonometry is rotated
     T xt[FD_NX], k[FD_NX], acc[FD_NX];
     Trig tt;
-    dynamics_fast(P, C, f.x0, f.t0, f.d0, k);                            // k1
+    dynamics_fast<STRAIGHT>(P, C, f.x0, f.t0, f.d0, k);                            // k1
 #pragma unroll
     for (int i = 0; i < 12; ++i) acc[i] = k[i];
 #pragma unroll
     for (int i = 3; i < 12; ++i) xt[i] = __builtin_fmaf(hdt, k[i], f.x0[i]);
     T dm = trig_rotate(f.t0, hdt * k[6], hdt * k[7], hdt * k[8], tt);
-    dynamics_fast(P, C, xt, tt, dm, k);                                  // k2
+    dynamics_fast<STRAIGHT>(P, C, xt, tt, dm, k);                        // k2
 #pragma unroll
     for (int i = 0; i < 12; ++i) acc[i] = __builtin_fmaf(T(2), k[i], acc[i]);
 #pragma unroll
     for (int i = 3; i < 12; ++i) xt[i] = __builtin_fmaf(hdt, k[i], f.x0[i]);
     dm = trig_rotate(f.t0, hdt * k[6], hdt * k[7], hdt * k[8], tt);
-    dynamics_fast(P, C, xt, tt, dm, k);                                  // k3
+    dynamics_fast<STRAIGHT>(P, C, xt, tt, dm, k);                        // k3
 #pragma unroll
     for (int i = 0; i < 12; ++i) acc[i] = __builtin_fmaf(T(2), k[i], acc[i]);
 #pragma unroll
     for (int i = 3; i < 12; ++i) xt[i] = __builtin_fmaf(fdt, k[i], f.x0[i]);
     dm = trig_rotate(f.t0, fdt * k[6], fdt * k[7], fdt * k[8], tt);
-    dynamics_fast(P, C, xt, tt, dm, k);                                  // k4
+    dynamics_fast<STRAIGHT>(P, C, xt, tt, dm, k);                        // k4
     T inc[FD_NX];
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
-        inc[i] = dt6 * (acc[i] + k[i]);
-        x[i] += S(inc[i]);
+        const T ksum = acc[i] + k[i];
+        inc[i] = dt6 * ksum;
+        // fp32 storage: the accumulate is spelled as the one fused instruction, so that no build's contraction heuristics decide
+        if constexpr (sizeof(S) == 4) x[i] = __builtin_fmaf(dt6, ksum, x[i]);
+        else x[i] += S(inc[i]);
         // the body-rate clamp (:273) sits in the straight-line path, as a select in the storage type: it is the STICKY clamp -- an
         // aircraft tumbling against it trips it on every sub-step, and behind the wave-level branch below it cost the wave
         // holding that aircraft 20 fix-ups per env step (at one wave per SIMD the launch lasts as long as its slowest wave)
-        if (i >= 9) x[i] = M<S>::abs(x[i]) > Lm.max_rate ? M<S>::copysign(Lm.max_rate, x[i]) : x[i];
+        if (STRAIGHT && i >= 9) x[i] = M<S>::abs(x[i]) > Lm.max_rate ? M<S>::copysign(Lm.max_rate, x[i]) : x[i];
         f.x0[i] = T(x[i]);
     }
     f.d0 = trig_rotate(f.t0, inc[6], inc[7], inc[8], f.t0);
@@ -709,7 +733,12 @@ FD_DEV void rk4_fast_step(const Params<float>& P, const Limits<S>& Lm, const Con
     // sincos rebuild behind one predicate that included the rate clamp: a wave holding one aircraft at that clamp ran 20
     // fix-ups + 19 rebuilds per env step, 100-111 k cycles for the RK4 phase against 71.6 k for an undisturbed wave --
     // scratch/phase_stamps.py, shader-clock stamps -- and the launch waited for it.)
-    const bool lim = !(vmax <= T(Lm.max_vel)) | (f.x0[2] > T(0)) | !(amax <= T(FD_PI));
+    bool lim = !(vmax <= T(Lm.max_vel)) | (f.x0[2] > T(0)) | !(amax <= T(FD_PI));
+    if constexpr (!STRAIGHT) {
+        // the same comparison the straight form makes, in the storage type (an fp32 copy can sit exactly on the limit while
+        // the stored value is a rounding beyond it)
+        lim |= (M<S>::abs(x[9]) > Lm.max_rate) | (M<S>::abs(x[10]) > Lm.max_rate) | (M<S>::abs(x[11]) > Lm.max_rate);
+    }
     const bool ang = !(__builtin_fabsf(f.x0[7]) <= T(Lm.max_pitch)) | !M<T>::finite(sum);
     if (FD_UNLIKELY(lim | ang)) {
         FD_DBG_COUNT(2)
@@ -725,6 +754,13 @@ FD_DEV void rk4_fast_step(const Params<float>& P, const Limits<S>& Lm, const Con
         } else {
 #pragma unroll
             for (int i = 3; i < 6; ++i) x[i] = clipv(x[i], -Lm.max_vel, Lm.max_vel);          // :262
+            if constexpr (!STRAIGHT) {
+#pragma unroll
+                for (int i = 9; i < 12; ++i) {                                                 // :273
+                    x[i] = M<S>::abs(x[i]) > Lm.max_rate ? M<S>::copysign(Lm.max_rate, x[i]) : x[i];
+                    f.x0[i] = T(x[i]);
+                }
+            }
             x[6] = wrap_state_angle<S, T>(x[6]);                                               // :266
             x[8] = wrap_state_angle<S, T>(x[8]);                                               // :270
             if (-x[2] < S(0)) {                                                                // :276-283 ground clamp
@@ -741,7 +777,7 @@ FD_DEV void rk4_fast_step(const Params<float>& P, const Limits<S>& Lm, const Con
 // ----- Simplified6DOF.step x n_sub: RK4 + post-clamps, simplified_6dof.py:247-291 ------------------------
 // fp64 evaluation (T = double): the reference's operation order, every clamp applied every step.
 // fp32 evaluation (T = float): rk4_fast_step above.
-template <typename S, typename T>
+template <typename S, typename T, bool STRAIGHT = true>
 FD_DEV void rk4_substeps(const Params<T>& P, const Limits<S>& Lm, const Controls<T>& C, S (&x)[FD_NX], S dt, int n_sub)
 {
     if constexpr (sizeof(T) == 8) {
@@ -770,7 +806,7 @@ FD_DEV void rk4_substeps(const Params<T>& P, const Limits<S>& Lm, const Controls
         FastRK f;
         f.init(x);                                               // the ONLY full sincos of the launch (rare blocks aside)
         const T hdt = T(S(0.5) * dt), fdt = T(dt), dt6 = T(dt / S(6));
-        for (int s = 0; s < n_sub; ++s) rk4_fast_step<S>(P, Lm, C, x, f, hdt, fdt, dt6);
+        for (int s = 0; s < n_sub; ++s) rk4_fast_step<S, STRAIGHT>(P, Lm, C, x, f, hdt, fdt, dt6);
     }
 }
 

@@ -745,7 +745,7 @@ rate_env_step_kernel(S* __restrict__ xs, typename EnvOf<S, T>::type* __restrict_
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
         FD_STAMP(1)
-        rk4_substeps<S, T>(P, Lm, C, x, dt_sub, ec.n_sub);
+        rk4_substeps<S, T, !OCC2>(P, Lm, C, x, dt_sub, ec.n_sub);
         FD_STAMP(2)
         if constexpr (sizeof(E) == sizeof(S)) e.time += E(ec.dt);                 // :241-242 (the reference's accumulated sum)
         else e.time = E(S(step + 1) * ec.dt);                                     // fp32 env words: exact product, not an fp32 running sum
@@ -837,9 +837,15 @@ rate_env_step_kernel(S* __restrict__ xs, typename EnvOf<S, T>::type* __restrict_
             env_apply_reset<S, E>(rec, ec.cmd_type, x, e);
             step = 0;
             episode += 1;
-            S airspeed, altitude;
-            airspeed_altitude<S>(x, airspeed, altitude);
-            env_observation<S, S, E>(x, e, airspeed, altitude, o);
+            // first observation of the new episode, in the glue type of this variant (an fp64 square root here is ~400 cycles
+            // that three waves in four pay once per launch in the steady state of a random-action fleet)
+            using A0 = typename GlueOf<S, T>::type;
+            A0 xa[FD_NX];
+#pragma unroll
+            for (int k = 0; k < FD_NX; ++k) xa[k] = A0(x[k]);
+            A0 airspeed, altitude;
+            airspeed_altitude<A0>(xa, airspeed, altitude);
+            env_observation<S, A0, E>(x, e, airspeed, altitude, o);
             if (pid_mode) for (int k = 0; k < 3 * FD_NPS; ++k) pid_state[k * n + i] = 0.0f;   // pid_agent.reset()
         }
 #pragma unroll

@@ -289,7 +289,7 @@ def test_register_capped_env_kernel_equals_uncapped_on_the_same_rows(precision):
                          0.3 + 0.5 * torch.rand((big, 1), device=a.device, generator=g)], 1).contiguous()
         oa, ra, ta, ua = a.step_device(act[:small].contiguous())
         ob, rb, tb, ub = b.step_device(act)
-        assert torch.equal(oa, ob[:small]) and torch.equal(ra, rb[:small]), k
+        assert torch.equal(oa, ob[:small]) and torch.equal(ra, rb[:small]), (k, float((oa - ob[:small]).abs().max()), float((ra - rb[:small]).abs().max()))
         assert torch.equal(ta, tb[:small]) and torch.equal(ua, ub[:small]), k
         ends += int((ta | ua).sum())
     assert torch.equal(a.x, b.x[:, :small]) and torch.equal(a.e, b.e[:, :small]) and torch.equal(a.ei, b.ei[:, :small])
