@@ -241,7 +241,9 @@ cascade_step_kernel(S* __restrict__ xs, float* __restrict__ pid_state /*[9*3][n]
             surf = waypoint_agent<G>(cfg, st, Cr, s_wps + idx * FD_NWP, f.x0, d, fdt);
             Controls<T> C;
             C.set(P, surf.elevator, surf.aileron, surf.rudder, surf.throttle);
-            rk4_fast_step<S>(P, Lm, C, x, f, hdt, fdt, dt6);
+            // controlled flight: an aircraft pushing against the rate clamp or flying sideways is an exception here, not a
+            // standing share of the fleet -- the special cases stay behind their wave-level branches (STRAIGHT = false)
+            rk4_fast_step<S, false>(P, Lm, C, x, f, hdt, fdt, dt6);
         }
     } else {
         for (int s = 0; s < n_steps; ++s) {
@@ -339,7 +341,7 @@ agent_step_kernel(int level, S* __restrict__ xs, float* __restrict__ pid_state /
             if (n_steps > 0) {
                 Controls<T> C;
                 C.set(P, surf.elevator, surf.aileron, surf.rudder, surf.throttle);
-                rk4_fast_step<S>(P, Lm, C, x, f, hdt, fdt, dt6);
+                rk4_fast_step<S, false>(P, Lm, C, x, f, hdt, fdt, dt6);
             }
         }
     } else {
