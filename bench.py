@@ -189,14 +189,17 @@ class Workload:
     def _rollout_step(self):
         """One policy + env step with every buffer updated in place (capture-safe)."""
         p = self.ppo
+        from hcrl_amd.fused import episode_flags
         nxt = p._state_bufs[1 - p._cur]
-        a, _v, _lp, new_states = p.policy.step(p.obs, p.states, p.episode_start, out_states=nxt)
+        fused_glue = p.policy._fused_ok(p.obs)
+        a, _v, _lp, new_states = p.policy.step(p.obs, p.states, p.episode_start, out_states=nxt, keep=p.keep, bump_noise=not fused_glue)
         _obs, _r, term, trunc = self.env.step_device(a)          # p.obs aliases the env's observation buffer
         for dst, src in zip(nxt, new_states):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src)
         p._cur = 1 - p._cur
-        p.episode_start.copy_((term | trunc).float())
+        # episode_start, keep = 1 - episode_start and the action-noise counter in one launch (as RecurrentPPO._rollout_body)
+        episode_flags(term, trunc, p.episode_start, p.keep, p.policy.noise_counter(p.device) if fused_glue else None)
 
     def step(self, k):
         if self.kind == "rollout":

@@ -668,6 +668,22 @@ ppo_loss_kernel(const float* __restrict__ mean /*[M][4]*/, const float* __restri
     }
 }
 
+// The glue between an env step and the next policy step of a rollout, ONE launch instead of five framework ones (or, cast,
+// copy, 1 - x, counter += 1: 26 us of a 330 us rollout step at 65 536 envs): episode_start = terminated | truncated as fp32,
+// keep = 1 - episode_start (what the recurrent cells mask their state with), and the device-side step counter of the action
+// noise (policy_heads / gaussian_head draw Philox blocks keyed by it) moves on by one.
+__global__ void __launch_bounds__(256)
+episode_flags_kernel(const uint8_t* __restrict__ terminated, const uint8_t* __restrict__ truncated, float* __restrict__ episode_start,
+                     float* __restrict__ keep, int32_t* __restrict__ counter, int64_t n)
+{
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i == 0 && counter) *counter += 1;
+    if (i >= n) return;
+    const bool done = (terminated[i] | truncated[i]) != 0;
+    if (episode_start) episode_start[i] = done ? 1.0f : 0.0f;
+    if (keep) keep[i] = done ? 0.0f : 1.0f;
+}
+
 inline unsigned blocks(int64_t n) { return unsigned((n + 255) / 256); }
 
 // grouped variant: rows come in segments of group_rows, segment j belonging to group j % n_groups (the [T][G][B] row order
@@ -856,6 +872,16 @@ int fdyn_lstm_cell0_bwd(const void* act, int bf16, const void* dh, void* dgates,
     else
         hipLaunchKernelGGL((lstm_cell0_bwd_kernel<float>), dim3(nblk), dim3(256), 0, (hipStream_t)stream,
                            (const float*)act, (const float*)dh, (float*)dgates, tv, H, vpb, bias_ws);
+    return int(hipGetLastError());
+}
+
+int fdyn_episode_flags(const uint8_t* terminated, const uint8_t* truncated, float* episode_start, float* keep, int32_t* counter,
+                       int64_t n, void* stream)
+{
+    if (n < 0) return FDYN_ERR_BAD_SIZE;
+    if (!terminated || !truncated) return FDYN_ERR_NULL;
+    hipLaunchKernelGGL(episode_flags_kernel, dim3(blocks(n < 1 ? 1 : n)), dim3(256), 0, (hipStream_t)stream, terminated, truncated,
+                       episode_start, keep, counter, n);
     return int(hipGetLastError());
 }
 

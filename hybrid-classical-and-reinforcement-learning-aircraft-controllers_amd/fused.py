@@ -565,6 +565,22 @@ def ppo_loss(mean, values, log_std, actions, old_logp, adv, ret, old_values, nor
     return loss, torch.stack([pl.detach(), vl.detach(), kl, cf])
 
 
+def episode_flags(terminated, truncated, episode_start, keep, counter=None):
+    """episode_start <- (terminated | truncated) as fp32, keep <- 1 - episode_start, counter += 1: the glue between an env step
+    and the next policy step in ONE launch (GPU); plain tensor ops elsewhere."""
+    if terminated.is_cuda and terminated.dtype == torch.uint8 and truncated.dtype == torch.uint8:
+        lib = _lib.load()
+        _lib.check(lib.fdyn_episode_flags(_lib.ptr(terminated), _lib.ptr(truncated), _lib.ptr(episode_start), _lib.ptr(keep),
+                                          _lib.ptr(counter), terminated.numel(), _lib.current_stream()), "episode_flags")
+        return
+    done = ((terminated != 0) | (truncated != 0)).float()
+    episode_start.copy_(done)
+    if keep is not None:
+        keep.copy_(1.0 - done)
+    if counter is not None:
+        counter.add_(1)
+
+
 def gae(rewards, values, episode_starts, last_values, last_dones, gamma: float, lam: float):
     """[T, N] fp32 rollout -> advantages, returns; one HIP launch on the GPU."""
     T, N = rewards.shape

@@ -291,11 +291,21 @@ class RateLSTMPolicy(nn.Module):
         # the two trunks; the 64 -> 4 and 64 -> 1 output layers are fused with the sampling (fdyn_policy_heads)
         return self._mlp_bf16(out[0], inf["pi"]), self._mlp_bf16(out[2], inf["vf"]), RNNStates(*out)
 
+    def noise_counter(self, device):
+        """The device-side step counter of the fused path's action noise (created on first use)."""
+        if not hasattr(self, "_noise_seed"):
+            self._noise_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            self._noise_step = torch.zeros(1, dtype=torch.int32, device=device)
+        return self._noise_step
+
     def step(self, obs, states: RNNStates, episode_start, deterministic: bool = False,
-             out_states: Optional[RNNStates] = None):
-        """obs [B,18], episode_start [B] (1 where the env was just reset) -> actions, values, log_probs, new states."""
+             out_states: Optional[RNNStates] = None, keep: Optional[torch.Tensor] = None, bump_noise: bool = True):
+        """obs [B,18], episode_start [B] (1 where the env was just reset) -> actions, values, log_probs, new states.
+        keep: 1 - episode_start if the caller already has it (fused.episode_flags writes both); bump_noise=False: the caller
+        moves the noise counter on itself (the same launch) -- a rollout loop then has no framework glue launches left."""
         if self._fused_ok(obs):
-            keep = (1.0 - episode_start.float()).contiguous()            # the mask is applied inside the kernel
+            if keep is None:
+                keep = (1.0 - episode_start.float()).contiguous()        # the mask is applied inside the kernel
             lat_pi, lat_vf, new_states = self._core_fused(obs, states, keep, out_states)
             # output heads + sampling + log-prob in ONE launch (in-kernel Philox keyed by a per-policy seed, the env index
             # and a step counter that lives on the device so a captured graph draws fresh noise on every replay)
@@ -306,10 +316,9 @@ class RateLSTMPolicy(nn.Module):
             actions = torch.empty((B, ACT_DIM), dtype=torch.float32, device=dev)
             logp = torch.empty(B, dtype=torch.float32, device=dev)
             value = torch.empty(B, dtype=torch.float32, device=dev)
-            if not hasattr(self, "_noise_seed"):
-                self._noise_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-                self._noise_step = torch.zeros(1, dtype=torch.int32, device=dev)      # device-side step counter
-            self._noise_step.add_(1)
+            self.noise_counter(dev)
+            if bump_noise:
+                self._noise_step.add_(1)
             _lib.check(_lib.load().fdyn_policy_heads(lat_pi.data_ptr(), lat_vf.data_ptr(), inf["act"][0].data_ptr(),
                                                      inf["act"][1].data_ptr(), inf["val"][0].data_ptr(), inf["val"][1].data_ptr(),
                                                      self.log_std.detach().float().contiguous().data_ptr(), self._noise_seed,

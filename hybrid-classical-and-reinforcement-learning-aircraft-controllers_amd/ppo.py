@@ -21,7 +21,7 @@ from typing import Optional
 import torch
 import torch.distributed as dist
 
-from .fused import ppo_loss
+from .fused import episode_flags, ppo_loss
 from .policy import RateLSTMPolicy, RNNStates
 
 
@@ -166,6 +166,7 @@ class RecurrentPPO:
         self.obs = env.reset()                           # aliases the env's observation buffer (rewritten every step)
         self._alloc_states(N)
         self.episode_start = torch.ones(N, **f32)
+        self.keep = torch.zeros(N, **f32)                # 1 - episode_start, kept in step by fused.episode_flags
         self.num_timesteps = 0
         self.ep_returns, self.ep_lengths = [], []
         self.last_stats = {}
@@ -197,6 +198,7 @@ class RecurrentPPO:
         for t in self.states:
             t.zero_()
         self.episode_start.fill_(1.0)
+        self.keep.zero_()
 
     def _rollout_body(self):
         """T policy+env steps, device ops only (no host sync): runs eagerly or under hipGraph capture.  All state lives in
@@ -204,9 +206,13 @@ class RecurrentPPO:
         env, pol, cfg = self.env, self.policy, self.cfg
         for dst, src in zip(self.rollout_states, self.states):
             dst.copy_(src)
+        # the fused policy path + uint8 env flags: episode_start, keep and the action-noise counter move in ONE launch per step
+        fused_glue = self.device.type == "cuda" and pol._fused_ok(self.obs)
+        counter = pol.noise_counter(self.device) if fused_glue else None
         for t in range(cfg.n_steps):
             nxt = self._state_bufs[1 - self._cur]             # the fused cells write the new state straight into it
-            actions, values, logp, new_states = pol.step(self.obs, self.states, self.episode_start, out_states=nxt)
+            actions, values, logp, new_states = pol.step(self.obs, self.states, self.episode_start, out_states=nxt,
+                                                         keep=self.keep, bump_noise=not fused_glue)
             self.buf_obs[t].copy_(self.obs); self.buf_act[t].copy_(actions); self.buf_val[t].copy_(values)
             self.buf_logp[t].copy_(logp); self.buf_start[t].copy_(self.episode_start)
             obs, rew, term, trunc = env.step_device(actions)          # clip happens in-kernel (rate_env.py:225)
@@ -238,7 +244,11 @@ class RecurrentPPO:
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src)                                # un-fused policy paths return fresh tensors
             self._cur = 1 - self._cur
-            self.episode_start.copy_((term | trunc).float())
+            if fused_glue and term.dtype == torch.uint8:
+                episode_flags(term, trunc, self.episode_start, self.keep, counter)
+            else:
+                self.episode_start.copy_((term | trunc).float())
+                self.keep.copy_(1.0 - self.episode_start)
 
     @torch.no_grad()
     def collect_rollout(self):

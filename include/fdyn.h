@@ -197,6 +197,10 @@ int fdyn_lstm_seq_bwd_bsum(const void* act, int bf16, const float* c_prev, const
 int fdyn_lstm_cell0_fwd(const void* gates, int bf16, void* h_out, void* act_out, int64_t B, int H, void* stream);
 int fdyn_lstm_cell0_bwd(const void* act, int bf16, const void* dh, void* dgates, float* bias_ws, int64_t rows_per_block,
                         int64_t B, int H, void* stream);
+/* Rollout glue in one launch: episode_start [n] = (terminated | truncated) as fp32, keep [n] = 1 - episode_start (either may be
+ * NULL), *counter += 1 (NULL = none: the device-side step counter of fdyn_policy_heads / fdyn_gaussian_head's action noise). */
+int fdyn_episode_flags(const uint8_t* terminated, const uint8_t* truncated, float* episode_start, float* keep, int32_t* counter,
+                       int64_t n, void* stream);
 /* out [N] = column sums of nb partial rows [nb][N] fp32 (two stages, no atomics); ws_mid [ceil(nb / 64)][N]. */
 int fdyn_colsum_partials(const float* partial, int64_t nb, int N, float* out, float* ws_mid, void* stream);
 /* Reductions of the PPO update, self-contained so that a hipGraph replay recomputes them (accumulators are cleared by a

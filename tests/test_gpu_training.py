@@ -219,6 +219,24 @@ def test_lstm_mfma_train_cell_matches_plain_torch_fp32(B, kx, kh):
     assert bool((nxt[:, :kx] == 9.0).all()) and bool((nxt[:, kx + H:] == 9.0).all())      # nothing outside its columns
 
 
+def test_episode_flags_kernel_matches_tensor_ops():
+    """fused.episode_flags (one launch: episode_start, keep = 1 - episode_start, noise counter += 1) against the tensor ops it
+    replaces, ragged size, repeated calls."""
+    from hcrl_amd.fused import episode_flags
+    torch.manual_seed(5)
+    n = 70001
+    start = torch.full((n,), 7.0, device="cuda"); keep = torch.full((n,), 7.0, device="cuda")
+    counter = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for k in range(3):
+        term = (torch.rand(n, device="cuda") < 0.1).to(torch.uint8)
+        trunc = (torch.rand(n, device="cuda") < 0.1).to(torch.uint8)
+        episode_flags(term, trunc, start, keep, counter)
+        ref = (term | trunc).float()
+        assert torch.equal(start, ref) and torch.equal(keep, 1.0 - ref) and int(counter.item()) == k + 1
+    episode_flags(term, trunc, start, None, None)                      # optional outputs
+    assert torch.equal(start, ref) and int(counter.item()) == 3
+
+
 def test_fused_rollout_step_matches_unfused_bf16_path():
     torch.manual_seed(0)
     p = RateLSTMPolicy(compute_dtype=torch.bfloat16).cuda()
