@@ -221,6 +221,14 @@ class RateLSTMPolicy(nn.Module):
             new["fe_img"] = pack_fe_weights(emb_l[0].weight, fe.lstm.weight_ih_l0, fe.lstm.weight_ih_l1, proj_l[0].weight)
             new["fe_bias"] = torch.cat([emb_l[0].bias.detach().float(), bias(fe.lstm, 0), bias(fe.lstm, 1),
                                         proj_l[0].bias.detach().float()]).contiguous()
+        # the two trunks as one kernel (csrc/policy_trunk.hip) when they have the reference's shape [256 -> 128 -> 64]
+        pi_l, vf_l = [m for m in self.pi_net if isinstance(m, nn.Linear)], [m for m in self.vf_net if isinstance(m, nn.Linear)]
+        if (len(pi_l) == 2 and len(vf_l) == 2 and all(l[0].weight.shape == (128, 256) and l[1].weight.shape == (64, 128) for l in (pi_l, vf_l))):
+            perm = torch.tensor([16 * (k // 16) + _KPERM16[k % 16] for k in range(128)], device=pi_l[0].weight.device)
+            new["trunk_w1"] = torch.stack([pi_l[0].weight.detach(), vf_l[0].weight.detach()]).to(bf).contiguous()
+            new["trunk_b1"] = torch.stack([pi_l[0].bias.detach(), vf_l[0].bias.detach()]).float().contiguous()
+            new["trunk_w2p"] = torch.stack([pi_l[1].weight.detach()[:, perm], vf_l[1].weight.detach()[:, perm]]).to(bf).contiguous()
+            new["trunk_b2"] = torch.stack([pi_l[1].bias.detach(), vf_l[1].bias.detach()]).float().contiguous()
         old = getattr(self, "_inf", None)
         if old is None:
             self._inf = new
@@ -289,6 +297,17 @@ class RateLSTMPolicy(nn.Module):
                                                B, H, st), "lstm_cell_mfma")
             out += [h, c]
         # the two trunks; the 64 -> 4 and 64 -> 1 output layers are fused with the sampling (fdyn_policy_heads)
+        if "trunk_w1" in inf and H == 256 and not os.environ.get("FDYN_NO_TRUNK"):
+            h_pi, h_vf = out[0], out[2]
+            assert h_pi.dtype == bf and h_vf.dtype == bf and h_pi.is_contiguous() and h_vf.is_contiguous() \
+                and h_pi.shape == (B, 256) and h_vf.shape == (B, 256) and inf["trunk_w1"].shape == (2, 128, 256) \
+                and inf["trunk_w2p"].shape == (2, 64, 128), "policy_trunks operand shapes"
+            lat_pi = torch.empty((B, 64), dtype=bf, device=dev)
+            lat_vf = torch.empty((B, 64), dtype=bf, device=dev)
+            _lib.check(lib.fdyn_policy_trunks(h_pi.data_ptr(), h_vf.data_ptr(), inf["trunk_w1"].data_ptr(), inf["trunk_b1"].data_ptr(),
+                                              inf["trunk_w2p"].data_ptr(), inf["trunk_b2"].data_ptr(), lat_pi.data_ptr(),
+                                              lat_vf.data_ptr(), B, st), "policy_trunks")
+            return lat_pi, lat_vf, RNNStates(*out)
         return self._mlp_bf16(out[0], inf["pi"]), self._mlp_bf16(out[2], inf["vf"]), RNNStates(*out)
 
     def noise_counter(self, device):

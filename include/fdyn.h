@@ -34,7 +34,8 @@
  *   fdyn_sensor_update_*   NoisySensorInterface.update       interfaces/sensor.py:199-243
  *   fdyn_sensor_observe    the same noise model on RateControlEnv observations (rate_env.py:374-408 layout)
  * Policy side (the reference delegates these to torch.nn.LSTM / SB3's PPO, which are not in its tree):
- *   fdyn_policy_features, fdyn_lstm_cell_mfma, fdyn_policy_heads, fdyn_gaussian_head   rollout: LSTM cell / output heads of
+ *   fdyn_policy_features, fdyn_lstm_cell_mfma, fdyn_policy_trunks, fdyn_policy_heads, fdyn_gaussian_head, fdyn_episode_flags
+ *                          rollout: features extractor / LSTM cell / trunks / output heads of
  *                          learned_controllers/networks/lstm_policy.py:13-136 (+ sb3_contrib's actor / critic LSTMs)
  *   fdyn_lstm_cell_fwd/_bwd, fdyn_lstm_seq_fwd/_bwd(_bsum),      BPTT point-wise cell update and its gradient (bias sums folded in),
  *   fdyn_lstm_cell0_fwd/_bwd, fdyn_colsum_partials                the zero-state three-gate layout of the features extractor
@@ -197,6 +198,13 @@ int fdyn_lstm_seq_bwd_bsum(const void* act, int bf16, const float* c_prev, const
 int fdyn_lstm_cell0_fwd(const void* gates, int bf16, void* h_out, void* act_out, int64_t B, int H, void* stream);
 int fdyn_lstm_cell0_bwd(const void* act, int bf16, const void* dh, void* dgates, float* bias_ws, int64_t rows_per_block,
                         int64_t B, int H, void* stream);
+/* The two trunks of the policy's mlp_extractor (pi and vf: Linear(256,128)+ReLU -> Linear(128,64)+ReLU; sb3_contrib MlpLstmPolicy
+ * with the reference's net_arch, learned_controllers/networks/lstm_policy.py:107-136) as ONE MFMA launch (csrc/policy_trunk.hip):
+ * h_pi, h_vf [B][256] bf16 -> lat_pi, lat_vf [B][64] bf16.  W1 [2][128][256] bf16 and b1 [2][128] fp32 (index 0 = pi, 1 = vf);
+ * W2p [2][64][128] bf16 with the columns of every block of 16 in the order (0 1 2 3 8 9 10 11 4 5 6 7 12 13 14 15) -- the
+ * first layer's output tile is the second layer's MFMA operand as it stands -- and b2 [2][64] fp32. */
+int fdyn_policy_trunks(const void* h_pi, const void* h_vf, const void* W1, const float* b1, const void* W2p, const float* b2,
+                       void* lat_pi, void* lat_vf, int64_t B, void* stream);
 /* Rollout glue in one launch: episode_start [n] = (terminated | truncated) as fp32, keep [n] = 1 - episode_start (either may be
  * NULL), *counter += 1 (NULL = none: the device-side step counter of fdyn_policy_heads / fdyn_gaussian_head's action noise). */
 int fdyn_episode_flags(const uint8_t* terminated, const uint8_t* truncated, float* episode_start, float* keep, int32_t* counter,

@@ -219,6 +219,33 @@ def test_lstm_mfma_train_cell_matches_plain_torch_fp32(B, kx, kh):
     assert bool((nxt[:, :kx] == 9.0).all()) and bool((nxt[:, kx + H:] == 9.0).all())      # nothing outside its columns
 
 
+@pytest.mark.parametrize("B", [77, 4096, 65536])
+def test_policy_trunks_kernel_matches_plain_torch_fp32(B):
+    """fdyn_policy_trunks (both trunks, two layers each, one MFMA launch; the first layer's output tile is the second layer's
+    operand) against plain fp32 PyTorch on the same bf16-rounded inputs, with the intermediate rounded to bf16 as the kernel
+    keeps it.  Asymmetric random data: a wrong fragment map or k permutation cannot pass."""
+    from hcrl_amd import _lib
+    from hcrl_amd.policy import _KPERM16
+    torch.manual_seed(B)
+    lib, bf = _lib.load(), torch.bfloat16
+    h = [(torch.randn(B, 256, device="cuda") * 0.6).to(bf) for _ in range(2)]
+    W1 = (torch.randn(2, 128, 256, device="cuda") * 0.08).to(bf)
+    b1 = torch.randn(2, 128, device="cuda") * 0.2
+    W2 = (torch.randn(2, 64, 128, device="cuda") * 0.1).to(bf)
+    b2 = torch.randn(2, 64, device="cuda") * 0.2
+    perm = torch.tensor([16 * (k // 16) + _KPERM16[k % 16] for k in range(128)], device="cuda")
+    W2p = W2[:, :, perm].contiguous()
+    lat = [torch.full((B, 64), 5.0, dtype=bf, device="cuda") for _ in range(2)]
+    _lib.check(lib.fdyn_policy_trunks(h[0].data_ptr(), h[1].data_ptr(), W1.data_ptr(), b1.data_ptr(), W2p.data_ptr(), b2.data_ptr(),
+                                      lat[0].data_ptr(), lat[1].data_ptr(), B, _lib.current_stream()), "policy_trunks")
+    torch.cuda.synchronize()
+    for g in range(2):
+        mid = torch.relu(h[g].float() @ W1[g].float().t() + b1[g]).to(bf).float()
+        ref = torch.relu(mid @ W2[g].float().t() + b2[g])
+        err = float((lat[g].float() - ref).abs().max())
+        assert err < 2e-2 * max(1.0, float(ref.abs().max())), (g, err)
+
+
 def test_episode_flags_kernel_matches_tensor_ops():
     """fused.episode_flags (one launch: episode_start, keep = 1 - episode_start, noise counter += 1) against the tensor ops it
     replaces, ragged size, repeated calls."""
