@@ -7,6 +7,8 @@
 // learned_controllers/networks/lstm_policy.py:107-136; the 64 -> 4 / 64 -> 1 output layers and the sampling are
 // fdyn_policy_heads.)  As four hipBLASLt GEMMs these layers took 2 x (16 + 10) us of a 300 us rollout step at 65 536 envs and
 // moved the 128-wide intermediate through HBM twice; the arithmetic is 10.7 GFLOP, the traffic that has to exist 84 MB.
+// Measured (rocprofv3, inside the rollout graph): 30.5 us -- first version 40.5 (weights staged by a load -> store loop: 20
+// dependent L2 round trips), 34 with the next tile of rows prefetched, 30.5 with the A fragments requested a k-step ahead.
 //
 // Scheme (the operand roles of policy_fe64.hip, compiler-managed registers): the WEIGHTS are the MFMA A operand, read from LDS
 // (both layers of a trunk stay resident: 66 + 17 KB), the ACTIVATIONS are the B operand in registers.  A 32x32 output tile is
@@ -16,6 +18,7 @@
 // (0 1 2 3 8 9 10 11 | 4 5 6 7 12 13 14 15), which the host folds into the weight image (policy.py: _KPERM16).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/fdyn.h"
 
 namespace {
@@ -23,11 +26,19 @@ namespace {
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));      // 16-byte piece (HIP's uint4 is a struct of unions: arrays of it stay in memory)
 
 constexpr int K1 = 256, N1 = 128, N2 = 64;
 constexpr int PADE = 8;                                  // bf16 elements (16 B) of LDS row padding: conflict-free ds_read_b128
 constexpr int ROW1 = K1 + PADE, ROW2 = N1 + PADE;
 constexpr int TRUNK_WGS = 128;                           // workgroups per trunk: 2 x 128 = one per CU on MI355X
+
+// compile-time loop: every index is a constant whatever the unroller decides (an array indexed by a loop the compiler leaves
+// rolled lives in scratch memory)
+template <int I, int N, class F> __device__ __forceinline__ void sfor(F&& f)
+{
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor<I + 1, N>(f); }
+}
 
 __global__ void __launch_bounds__(256, 1)
 policy_trunk_kernel(const uint16_t* __restrict__ h_pi, const uint16_t* __restrict__ h_vf /*[B][256] bf16*/,
@@ -57,26 +68,26 @@ policy_trunk_kernel(const uint16_t* __restrict__ h_pi, const uint16_t* __restric
     {
         constexpr int P1 = N1 * (K1 / 8) / 256, P2 = N2 * (N1 / 8) / 256;          // 16 and 4 pieces per thread
         static_assert(N1 * (K1 / 8) % 256 == 0 && N2 * (N1 / 8) % 256 == 0, "whole pieces per thread");
-        uint4 w1r[P1], w2r[P2];
+        u32x4_t w1r[P1], w2r[P2];
 #pragma unroll
         for (int i = 0; i < P1; ++i) {
             const int v = tid + 256 * i, row = v / (K1 / 8), c = v % (K1 / 8);
-            w1r[i] = *reinterpret_cast<const uint4*>(W1 + (int64_t(trunk) * N1 + row) * K1 + c * 8);
+            w1r[i] = *reinterpret_cast<const u32x4_t*>(W1 + (int64_t(trunk) * N1 + row) * K1 + c * 8);
         }
 #pragma unroll
         for (int i = 0; i < P2; ++i) {
             const int v = tid + 256 * i, row = v / (N1 / 8), c = v % (N1 / 8);
-            w2r[i] = *reinterpret_cast<const uint4*>(W2p + (int64_t(trunk) * N2 + row) * N1 + c * 8);
+            w2r[i] = *reinterpret_cast<const u32x4_t*>(W2p + (int64_t(trunk) * N2 + row) * N1 + c * 8);
         }
 #pragma unroll
         for (int i = 0; i < P1; ++i) {
             const int v = tid + 256 * i, row = v / (K1 / 8), c = v % (K1 / 8);
-            *reinterpret_cast<uint4*>(s_w1 + row * ROW1 + c * 8) = w1r[i];
+            *reinterpret_cast<u32x4_t*>(s_w1 + row * ROW1 + c * 8) = w1r[i];
         }
 #pragma unroll
         for (int i = 0; i < P2; ++i) {
             const int v = tid + 256 * i, row = v / (N1 / 8), c = v % (N1 / 8);
-            *reinterpret_cast<uint4*>(s_w2 + row * ROW2 + c * 8) = w2r[i];
+            *reinterpret_cast<u32x4_t*>(s_w2 + row * ROW2 + c * 8) = w2r[i];
         }
     }
     if (tid < N1) s_b1[tid] = b1[trunk * N1 + tid];
@@ -85,47 +96,66 @@ policy_trunk_kernel(const uint16_t* __restrict__ h_pi, const uint16_t* __restric
 
     const int64_t wg_first = int64_t(blockIdx.x) * rows_per_wg;
     const int64_t wg_end = wg_first + rows_per_wg < B ? wg_first + rows_per_wg : B;
+    // A wave's tile of 32 input rows travels HBM -> registers -> LDS -> B fragments, and the NEXT tile's loads are issued as soon
+    // as the current one has been written to LDS: all 1024 waves of the launch run in phase (one per SIMD), so an un-prefetched
+    // tile is a 17 MB burst that every wave waits for, four times per launch (piece p = 64 i + lane: row p / 32, 16-byte
+    // column p % 32; rows past the end read the last row).
+    u32x4_t pieces[K1 / 16];
+    auto request = [&](int64_t first) {
+        sfor<0, K1 / 16>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const int pc = 64 * i + lane, prow = pc >> 5, pcol = pc & 31;
+            const int64_t src = first + prow < B ? first + prow : B - 1;
+            pieces[i] = *reinterpret_cast<const u32x4_t*>(h + src * K1 + pcol * 8);
+        });
+    };
+    if (wg_first + wave * 32 < wg_end) request(wg_first + wave * 32);
     for (int64_t row0 = wg_first + wave * 32; row0 < wg_end; row0 += 128) {          // wave-uniform
         const int64_t my_row = row0 + r;
-        const int64_t lrow = my_row < B ? my_row : B - 1;                              // rows past the end read the last row, store nothing
-        // ---- the wave's 32 rows -> LDS (piece p = 64 i + lane: row p / 32, 16-byte column p % 32)
-        (void)lrow;
         uint16_t* sh = s_h[wave];
-        {
-            uint4 pieces[K1 / 16];
-#pragma unroll
-            for (int i = 0; i < K1 / 16; ++i) {
-                const int pc = 64 * i + lane, prow = pc >> 5, pcol = pc & 31;
-                const int64_t src = row0 + prow < B ? row0 + prow : B - 1;             // rows past the end read the last row
-                pieces[i] = *reinterpret_cast<const uint4*>(h + src * K1 + pcol * 8);
-            }
-            // (a wave's LDS operations execute in program order: the previous iteration's fragment reads precede these writes,
-            // the reads below follow them -- no barrier, the region is this wave's own)
-#pragma unroll
-            for (int i = 0; i < K1 / 16; ++i) {
-                const int pc = 64 * i + lane, prow = pc >> 5, pcol = pc & 31;
-                *reinterpret_cast<uint4*>(sh + prow * ROW1 + pcol * 8) = pieces[i];
-            }
-        }
+        // (a wave's LDS operations execute in program order: the previous iteration's fragment reads precede these writes, the
+        // reads below follow them -- no barrier, the region is this wave's own)
+        sfor<0, K1 / 16>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const int pc = 64 * i + lane, prow = pc >> 5, pcol = pc & 31;
+            *reinterpret_cast<u32x4_t*>(sh + prow * ROW1 + pcol * 8) = pieces[i];
+        });
+        if (row0 + 128 < wg_end) request(row0 + 128);
         // ---- layer-1 B fragments: lane (b, hf) holds h[b][16 s + 8 hf .. + 7] for every k-step s
         bf16x8_t bx[K1 / 16];
         const uint16_t* hr = sh + r * ROW1 + 8 * hf;
 #pragma unroll
         for (int s = 0; s < K1 / 16; ++s) bx[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(hr + 16 * s));
 
-        // ---- layer 1: four 32-feature tiles; each leaves two B fragments of layer 2
+        // ---- layer 1: four 32-feature tiles, k outer: the four accumulator chains are independent, and the A fragments of k-step
+        // s + 1 are requested from LDS before the MFMAs of k-step s are issued (left to the compiler every ds_read_b128 landed in
+        // the registers its MFMA then consumed: read, wait, MFMA -- each MFMA paid the LDS latency).  The base address is
+        // laundered once per tile of rows: the fragment reads must stay in this loop (hoisted out of it, the 80 fragments of a
+        // trunk are 320 registers and the row prefetch above spills).
+        f32x16_t acc1[N1 / 32];
+#pragma unroll
+        for (int t = 0; t < N1 / 32; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc1[t][e] = 0.0f;
+        const uint16_t* wr1 = s_w1 + r * ROW1 + 8 * hf;
+        asm volatile("" : "+v"(wr1));
+        u32x4_t an[2][N1 / 32];
+#pragma unroll
+        for (int t = 0; t < N1 / 32; ++t) an[0][t] = *reinterpret_cast<const u32x4_t*>(wr1 + 32 * t * ROW1);
+#pragma unroll
+        for (int s = 0; s < K1 / 16; ++s) {
+            if (s + 1 < K1 / 16) {
+#pragma unroll
+                for (int t = 0; t < N1 / 32; ++t) an[(s + 1) & 1][t] = *reinterpret_cast<const u32x4_t*>(wr1 + 32 * t * ROW1 + 16 * (s + 1));
+            }
+#pragma unroll
+            for (int t = 0; t < N1 / 32; ++t)
+                acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, an[s & 1][t]), bx[s], acc1[t], 0, 0, 0);
+        }
+        // bias + ReLU + bf16: elements 8 q .. 8 q + 7 of tile t are the B fragment of layer-2 k-step 2 t + q
         bf16x8_t b2f[N1 / 16];
 #pragma unroll
         for (int t = 0; t < N1 / 32; ++t) {
-            f32x16_t acc;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-            const uint16_t* wr = s_w1 + (32 * t + r) * ROW1 + 8 * hf;
-#pragma unroll
-            for (int s = 0; s < K1 / 16; ++s) {
-                const bf16x8_t a = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wr + 16 * s));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bx[s], acc, 0, 0, 0);
-            }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 bf16x8_t f;
@@ -136,7 +166,7 @@ policy_trunk_kernel(const uint16_t* __restrict__ h_pi, const uint16_t* __restric
                     const float bv[4] = { bb.x, bb.y, bb.z, bb.w };
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const float v = acc[4 * j + i] + bv[i];
+                        const float v = acc1[t][4 * j + i] + bv[i];
                         f[4 * jj + i] = static_cast<__bf16>(v > 0.0f ? v : 0.0f);
                     }
                 }
@@ -144,18 +174,29 @@ policy_trunk_kernel(const uint16_t* __restrict__ h_pi, const uint16_t* __restric
             }
         }
 
-        // ---- layer 2: two 32-feature tiles, stored as 8-byte pieces (4 adjacent features of this lane's own row)
+        // ---- layer 2: two 32-feature tiles (same arrangement), stored as 8-byte pieces (4 adjacent features of this lane's row)
+        f32x16_t acc2[N2 / 32];
+#pragma unroll
+        for (int t = 0; t < N2 / 32; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc2[t][e] = 0.0f;
+        const uint16_t* wr2 = s_w2 + r * ROW2 + 8 * hf;
+        asm volatile("" : "+v"(wr2));
+        u32x4_t cn[2][N2 / 32];
+#pragma unroll
+        for (int t = 0; t < N2 / 32; ++t) cn[0][t] = *reinterpret_cast<const u32x4_t*>(wr2 + 32 * t * ROW2);
+#pragma unroll
+        for (int s = 0; s < N1 / 16; ++s) {
+            if (s + 1 < N1 / 16) {
+#pragma unroll
+                for (int t = 0; t < N2 / 32; ++t) cn[(s + 1) & 1][t] = *reinterpret_cast<const u32x4_t*>(wr2 + 32 * t * ROW2 + 16 * (s + 1));
+            }
+#pragma unroll
+            for (int t = 0; t < N2 / 32; ++t)
+                acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, cn[s & 1][t]), b2f[s], acc2[t], 0, 0, 0);
+        }
 #pragma unroll
         for (int t = 0; t < N2 / 32; ++t) {
-            f32x16_t acc;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-            const uint16_t* wr = s_w2 + (32 * t + r) * ROW2 + 8 * hf;
-#pragma unroll
-            for (int s = 0; s < N1 / 16; ++s) {
-                const bf16x8_t a = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wr + 16 * s));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b2f[s], acc, 0, 0, 0);
-            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float4 bb = *reinterpret_cast<const float4*>(s_b2 + 32 * t + 8 * j + 4 * hf);
@@ -163,7 +204,7 @@ policy_trunk_kernel(const uint16_t* __restrict__ h_pi, const uint16_t* __restric
                 bf16x4_t o;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float v = acc[4 * j + i] + bv[i];
+                    const float v = acc2[t][4 * j + i] + bv[i];
                     o[i] = static_cast<__bf16>(v > 0.0f ? v : 0.0f);
                 }
                 if (my_row < B) *reinterpret_cast<uint2*>(lat + my_row * N2 + 32 * t + 8 * j + 4 * hf) = __builtin_bit_cast(uint2, o);
