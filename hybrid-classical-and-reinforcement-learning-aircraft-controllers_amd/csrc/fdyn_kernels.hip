@@ -670,14 +670,23 @@ rate_env_step_kernel(S* __restrict__ xs, typename EnvOf<S, T>::type* __restrict_
     int32_t step = 0, episode = 0;
     int ty = 0;
     float4 av = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    // The reset record of an env that ends in this launch depends only on (seed, env, episode): with device sampling it is drawn
+    // HERE, while the state loads are in flight -- at one wave per SIMD every wave of the launch loads at the same moment, the
+    // 13 MB burst takes ~7 k cycles and the wave has nothing else to do, whereas at the end of the step the four Philox blocks
+    // (80 quarter-rate 64-bit multiplies, ~2.5 k cycles) were paid by three waves in four, the slowest ones included.  The
+    // episode counter is therefore loaded FIRST (loads return in order).  The register-capped build keeps the lazy draw: its
+    // neighbour wave hides it, and 24 more live registers would spill.
+    S rec_pre[FD_NR];
+    const bool pre_drawn = !OCC2 && pool == nullptr && auto_reset != 0;
     if (active) {
+        step = eis[FD_EI_STEP * n + i];
+        episode = eis[FD_EI_EPISODE * n + i];
 #pragma unroll
         for (int k = 0; k < FD_NX; ++k) x[k] = xs[k * n + i];
         env_load<E>(e, es, n, i, uses_sched);
-        step = eis[FD_EI_STEP * n + i];
-        episode = eis[FD_EI_EPISODE * n + i];
         if (actions) av = reinterpret_cast<const float4*>(actions)[i];
         ty = lane_type(type, i, n_types);
+        if (pre_drawn) device_reset_record<S>(seed, uint32_t(i), uint32_t(episode), ec, rec_pre);
     }
     stage_params<sizeof(T) == 4>(s_params, params, n_types);
     if (pid_mode) {
@@ -835,7 +844,12 @@ rate_env_step_kernel(S* __restrict__ xs, typename EnvOf<S, T>::type* __restrict_
     if (active) {
         if (done && auto_reset) {
             S rec[FD_NR];
-            fetch_reset_record<S>(pool, pool_depth, seed, i, episode, ec, rec);
+            if (pre_drawn) {
+#pragma unroll
+                for (int k = 0; k < FD_NR; ++k) rec[k] = rec_pre[k];
+            } else {
+                fetch_reset_record<S>(pool, pool_depth, seed, i, episode, ec, rec);
+            }
             env_apply_reset<S, E>(rec, ec.cmd_type, x, e);
             step = 0;
             episode += 1;

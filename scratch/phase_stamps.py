@@ -16,8 +16,12 @@ env = GpuRateVecEnv(n, "medium", 10.0, 0.02, "step", seed=0, precision="mixed", 
 env.reset()
 dev = env.device
 g = torch.Generator(device=dev).manual_seed(1)
-acts = [torch.cat([(torch.rand((n, 3), device=dev, generator=g) - 0.5) * 0.6, 0.4 + 0.4 * torch.rand((n, 1), device=dev, generator=g)], 1).contiguous()
-        for _ in range(4)]
+mode = sys.argv[3] if len(sys.argv) > 3 else "bench"
+if mode == "normal":          # what an untrained Gaussian policy emits: N(0, 1) per channel (the env clips)
+    acts = [torch.randn((n, 4), device=dev, generator=g).contiguous() for _ in range(4)]
+else:
+    acts = [torch.cat([(torch.rand((n, 3), device=dev, generator=g) - 0.5) * 0.6, 0.4 + 0.4 * torch.rand((n, 1), device=dev, generator=g)], 1).contiguous()
+            for _ in range(4)]
 warm = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 for k in range(warm):
     env.step_device(acts[k % 4])
