@@ -37,6 +37,7 @@ SIGNATURES = {
     "fdyn_lstm_seq_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _i, _p]),
     "fdyn_lstm_seq_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _i64, _i, _p]),
     "fdyn_lstm_seq_bwd_bsum": (_i, [_p, _i, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i, _p]),
+    "fdyn_lstm_seq_bwd_pre": (_i, [_p, _i, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i, _p]),
     "fdyn_lstm_cell0_fwd": (_i, [_p, _i, _p, _p, _i64, _i, _p]),
     "fdyn_lstm_cell0_bwd": (_i, [_p, _i, _p, _p, _p, _i64, _i64, _i, _p]),
     "fdyn_colsum_partials": (_i, [_p, _i64, _i, _p, _p, _p]),

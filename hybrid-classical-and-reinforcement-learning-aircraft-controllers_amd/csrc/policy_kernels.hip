@@ -149,7 +149,11 @@ lstm_cell_bwd_kernel(const GT* act /*may alias dgates: every lane reads its 4 x 
                      float* __restrict__ dc_prev, int64_t total_vec, int H, int64_t vecs_per_block, float* __restrict__ bias_ws,
                      const float* __restrict__ keep = nullptr /*[B]: the forward used keep * c_prev*/,
                      const GT* __restrict__ dh2 = nullptr /*second dh addend, row stride dh2_stride, scaled by dh2_keep*/,
-                     int64_t dh2_stride = 0, const float* __restrict__ dh2_keep = nullptr)
+                     int64_t dh2_stride = 0, const float* __restrict__ dh2_keep = nullptr,
+                     const GT* __restrict__ pre_bias = nullptr /*non-null: `act` holds the PRE-activations (the GEMM's output, which
+                     the forward then never had to re-write as activations: 8 of its 28 bytes per hidden unit); the bias
+                     [rows / pre_group_rows][4H] is added and the gate non-linearities are re-evaluated here*/,
+                     int64_t pre_group_rows = 1)
 {
     __shared__ float s_red[256 * VEC * 4];
     const int hv = H / VEC;
@@ -168,6 +172,16 @@ lstm_cell_bwd_kernel(const GT* act /*may alias dgates: every lane reads its 4 x 
         float ai[VEC], af[VEC], ag[VEC], ao[VEC], cp[VEC], cn[VEC], dhv[VEC], dcn[VEC];
         float di[VEC], df[VEC], dg[VEC], dov[VEC], dcp[VEC];
         Vec8<GT>::load(a0, ai); Vec8<GT>::load(a0 + H, af); Vec8<GT>::load(a0 + 2 * H, ag); Vec8<GT>::load(a0 + 3 * H, ao);
+        if (pre_bias) {
+            const GT* b0 = pre_bias + (row / pre_group_rows) * 4 * H + j;
+            float bi[VEC], bf_[VEC], bg[VEC], bo[VEC];
+            Vec8<GT>::load(b0, bi); Vec8<GT>::load(b0 + H, bf_); Vec8<GT>::load(b0 + 2 * H, bg); Vec8<GT>::load(b0 + 3 * H, bo);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                ai[k] = sigmoidf_(ai[k] + bi[k]); af[k] = sigmoidf_(af[k] + bf_[k]);
+                ag[k] = tanhf_(ag[k] + bg[k]); ao[k] = sigmoidf_(ao[k] + bo[k]);
+            }
+        }
         if (c_new) {
             Vec8<float>::load(c_new + row * H + j, cn);
         } else {                                              // zero-state cell whose c was not kept: c = i * g from the saved gates
@@ -803,7 +817,8 @@ int fdyn_lstm_seq_fwd(const void* gates, int gates_bf16, const float* c_prev, co
 
 static int seq_bwd_launch(const void* act, int bf16, const float* c_prev, const float* keep, const float* c_new, const void* dh,
                           const void* dh2, int64_t dh2_stride, const float* dh2_keep, const float* dc_next, void* dgates,
-                          float* dc_prev, float* bias_ws, int64_t rows_per_block, int64_t B, int H, void* stream)
+                          float* dc_prev, float* bias_ws, int64_t rows_per_block, int64_t B, int H, void* stream,
+                          const void* pre_bias = nullptr, int64_t pre_group_rows = 1)
 {
     if (B < 0 || H <= 0 || H % VEC || (dh2 && dh2_stride < H)) return FDYN_ERR_BAD_SIZE;
     if (!act || !c_prev || !c_new || !dh || !dgates || !dc_prev) return FDYN_ERR_NULL;
@@ -816,11 +831,11 @@ static int seq_bwd_launch(const void* act, int bf16, const float* c_prev, const 
     if (bf16)
         hipLaunchKernelGGL((lstm_cell_bwd_kernel<uint16_t>), dim3(nblk), dim3(256), 0, (hipStream_t)stream,
                            (const uint16_t*)act, c_prev, c_new, (const uint16_t*)dh, dc_next, (uint16_t*)dgates, dc_prev, tv, H, vpb, bias_ws,
-                           keep, (const uint16_t*)dh2, dh2_stride, dh2_keep);
+                           keep, (const uint16_t*)dh2, dh2_stride, dh2_keep, (const uint16_t*)pre_bias, pre_group_rows);
     else
         hipLaunchKernelGGL((lstm_cell_bwd_kernel<float>), dim3(nblk), dim3(256), 0, (hipStream_t)stream,
                            (const float*)act, c_prev, c_new, (const float*)dh, dc_next, (float*)dgates, dc_prev, tv, H, vpb, bias_ws,
-                           keep, (const float*)dh2, dh2_stride, dh2_keep);
+                           keep, (const float*)dh2, dh2_stride, dh2_keep, (const float*)pre_bias, pre_group_rows);
     return int(hipGetLastError());
 }
 
@@ -838,6 +853,16 @@ int fdyn_lstm_seq_bwd_bsum(const void* act, int bf16, const float* c_prev, const
     if (!bias_ws) return FDYN_ERR_NULL;
     return seq_bwd_launch(act, bf16, c_prev, keep, c_new, dh, dh2, dh2_stride, dh2_keep, dc_next, dgates, dc_prev, bias_ws, rows_per_block,
                           B, H, stream);
+}
+
+int fdyn_lstm_seq_bwd_pre(const void* gates, int bf16, const void* bias, int64_t group_rows, const float* c_prev, const float* keep,
+                          const float* c_new, const void* dh, const void* dh2, int64_t dh2_stride, const float* dh2_keep,
+                          const float* dc_next, void* dgates, float* dc_prev, float* bias_ws, int64_t rows_per_block, int64_t B, int H,
+                          void* stream)
+{
+    if (!bias || group_rows < 1) return bias ? FDYN_ERR_BAD_SIZE : FDYN_ERR_NULL;
+    return seq_bwd_launch(gates, bf16, c_prev, keep, c_new, dh, dh2, dh2_stride, dh2_keep, dc_next, dgates, dc_prev, bias_ws, rows_per_block,
+                          B, H, stream, bias, group_rows);
 }
 
 int fdyn_lstm_cell0_fwd(const void* gates, int bf16, void* h_out, void* act_out, int64_t B, int H, void* stream)

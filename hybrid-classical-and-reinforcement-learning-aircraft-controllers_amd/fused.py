@@ -156,8 +156,13 @@ class _SplitKLinearFn(torch.autograd.Function):
         return dx, dw, db
 
 
-def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], min_rows: int = 8192) -> torch.Tensor:
-    """`F.linear` for the training path: tall inputs on the GPU take the split-K weight gradient."""
+def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], min_rows: int = 1) -> torch.Tensor:
+    """`F.linear` for the training path: on the GPU the weight gradient is the split-K GEMM (one plain GEMM for short inputs) and
+    the bias gradient OUR column sum.  min_rows = 1, i.e. always: the framework's own bias-gradient reduction is one of the
+    reductions that return garbage from the second replay of a captured graph on this stack -- with the
+    former threshold of 8192 rows a SMALL training configuration (512 envs x 8 steps in 4 slices) trained on garbage bias
+    gradients under the update graph and went to NaN in its third iteration (scratch/dbg_graph_grads.py compares replayed and
+    eager gradients parameter by parameter; tests/test_gpu_training.py::test_small_update_graph_replays_match_eager pins it)."""
     rows = x.numel() // max(x.shape[-1], 1)
     if x.is_cuda and rows >= min_rows and torch.is_grad_enabled() and (w.requires_grad or x.requires_grad):
         return _SplitKLinearFn.apply(x, w, b)
@@ -423,17 +428,21 @@ class _LSTMSequenceFn(torch.autograd.Function):
             T_done = T
         else:
             T_done = 0
+        # un-fused steps: the GEMM writes its pre-activations straight into the slot the backward pass reads (act[t]); the
+        # point-wise kernel does not re-write them as activations (8 of its 28 bytes per hidden unit) -- the backward kernel
+        # re-evaluates the non-linearities from the same rounded values (fdyn_lstm_seq_bwd_pre)
+        pre = need and T_done == 0 and not os.environ.get("FDYN_NO_PRE")
         for t in range(T_done, T):
-            gates = torch.bmm(x_all[t], wT)                                  # [G, B, 4H]; the bias is added in the cell kernel
+            gates = torch.bmm(x_all[t], wT, out=act[t]) if pre else torch.bmm(x_all[t], wT)      # [G, B, 4H]; bias: in the cell kernel
             last = t == T - 1
             _lib.check(lib.fdyn_lstm_seq_fwd(gates.data_ptr(), int(bf16), c_all[t].data_ptr(), keep_rows[t].data_ptr(),
-                                             h_seq[t].data_ptr(), c_all[t + 1].data_ptr(), act[t].data_ptr() if need else None,
+                                             h_seq[t].data_ptr(), c_all[t + 1].data_ptr(), act[t].data_ptr() if (need and not pre) else None,
                                              None if last else x_all[t + 1].data_ptr() + kx * esz, K,
                                              None if last else keep_rows[t + 1].data_ptr(), b.data_ptr(), B, R, H, st),
                        "lstm_seq_fwd")
         if need:
-            ctx.save_for_backward(x_all, act, c_all, keep_rows, w)
-            ctx.kx, ctx.G, ctx.param_dtypes = kx, G, tuple(p.dtype for p in params)
+            ctx.save_for_backward(x_all, act, c_all, keep_rows, w, b)
+            ctx.kx, ctx.G, ctx.param_dtypes, ctx.pre = kx, G, tuple(p.dtype for p in params), pre
         ctx.mark_non_differentiable(c_all)
         ctx.set_materialize_grads(False)          # no [T+1, G, B, H] zero tensor for the state output nobody differentiates
         return h_seq, c_all
@@ -443,7 +452,7 @@ class _LSTMSequenceFn(torch.autograd.Function):
         if dh_seq is None:
             return (None,) * (4 + 4 * ctx.G)
         lib = _lib.load()
-        x_all, act, c_all, keep_rows, w = ctx.saved_tensors
+        x_all, act, c_all, keep_rows, w, b = ctx.saved_tensors
         T, G, B, K = x_all.shape
         H, kx, dt, dev = c_all.shape[-1], ctx.kx, x_all.dtype, x_all.device
         bf16 = dt == torch.bfloat16
@@ -464,7 +473,10 @@ class _LSTMSequenceFn(torch.autograd.Function):
                     None if last else dcat[t + 1].data_ptr() + kx * esz, K,
                     None if last else keep_rows[t + 1].data_ptr(),
                     None if last else dc[(t + 1) & 1].data_ptr(), act[t].data_ptr(), dc[t & 1].data_ptr())
-            if rpb:
+            if ctx.pre:
+                _lib.check(lib.fdyn_lstm_seq_bwd_pre(args[0], args[1], b.data_ptr(), B, *args[2:], bws[t].data_ptr() if rpb else None,
+                                                     rpb, R, H, st), "lstm_seq_bwd_pre")
+            elif rpb:
                 _lib.check(lib.fdyn_lstm_seq_bwd_bsum(*args, bws[t].data_ptr(), rpb, R, H, st), "lstm_seq_bwd_bsum")
             else:
                 _lib.check(lib.fdyn_lstm_seq_bwd(*args, R, H, st), "lstm_seq_bwd")

@@ -190,6 +190,13 @@ int fdyn_lstm_seq_bwd(const void* act, int bf16, const float* c_prev, const floa
 int fdyn_lstm_seq_bwd_bsum(const void* act, int bf16, const float* c_prev, const float* keep, const float* c_new, const void* dh,
                            const void* dh2, int64_t dh2_stride, const float* dh2_keep, const float* dc_next, void* dgates,
                            float* dc_prev, float* bias_ws, int64_t rows_per_block, int64_t B, int H, void* stream);
+/* The same backward step when the forward kept the PRE-activations instead of the activated gates (the GEMM wrote them, the
+ * forward point-wise pass never re-wrote them: 8 of its 28 bytes per hidden unit): `gates` [B][4H] + bias [B / group_rows][4H]
+ * (gates dtype) are activated again here; everything else as fdyn_lstm_seq_bwd(_bsum) (bias_ws may be NULL). */
+int fdyn_lstm_seq_bwd_pre(const void* gates, int bf16, const void* bias, int64_t group_rows, const float* c_prev, const float* keep,
+                          const float* c_new, const void* dh, const void* dh2, int64_t dh2_stride, const float* dh2_keep,
+                          const float* dc_next, void* dgates, float* dc_prev, float* bias_ws, int64_t rows_per_block, int64_t B, int H,
+                          void* stream);
 /* Zero-state cell in the THREE-gate layout (i, g, o along 3H): the features extractor's LSTM layers, which the reference runs
  * on a length-1 sequence without carried state (learned_controllers/networks/lstm_policy.py:75-92), so the forget gate
  * multiplies zero and neither its pre-activation nor its gradient exists.  fwd: gates [B][3H] (bias added by the GEMM) ->

@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/c39
+timeout -k 10 900 python -m pytest tests/test_gpu_training.py tests/test_ppo_distributed.py -x -q -m gpu > gpurun_out/c39/tests.log 2>&1; echo "pytest rc $?"; tail -4 gpurun_out/c39/tests.log
+for i in 1 2; do timeout -k 10 300 python bench.py --workload train --ppo-minibatches 2 --steps 8 --warmup 2 --no-cpu-baseline --no-extras | cut -c100-220; done

@@ -587,15 +587,18 @@ def test_fused_ppo_loss_and_colsum_match_torch():
             assert got.shape == (g_, n) and float((got.double() - want).abs().max()) < 2e-2, (dt, t_, g_, b_, n)
 
 
-def test_update_graph_replays_match_eager_at_training_size():
+@pytest.mark.parametrize("N,T,n_mb", [(16384, 64, 8), (512, 8, 4)])
+def test_update_graph_replays_match_eager_at_training_size(N, T, n_mb):
     """Six replays of the captured forward+backward on fresh slices (16 384 envs x 64 steps, bf16 policy) against the eager
     pass on the same static buffers: every parameter gradient and the loss statistics.  (Guards the graph path against
-    stale / uninitialised reductions under replay.)"""
-    env = GpuRateVecEnv(16384, "easy", 10.0, 0.02, "step", seed=42, precision="mixed", sampling="device")
-    m = RecurrentPPO(env, RateLSTMPolicy(compute_dtype=torch.bfloat16), PPOConfig(n_steps=64, n_epochs=1, n_minibatches=8,
+    stale / uninitialised reductions under replay.)  The SMALL configuration (512 envs x 8 steps in 4 slices = 1024 rows per
+    layer) is the one that used to fall below fused.linear's row threshold and take the framework's bias-gradient reduction:
+    garbage from the second replay on, NaN weights in the third PPO iteration."""
+    env = GpuRateVecEnv(N, "easy", 10.0, 0.02, "step", seed=42, precision="mixed", sampling="device")
+    m = RecurrentPPO(env, RateLSTMPolicy(compute_dtype=torch.bfloat16), PPOConfig(n_steps=T, n_epochs=1, n_minibatches=n_mb,
                                                                                   reward_scale=0.02), seed=42, use_graph=False)
     m.collect_rollout()
-    N, mb = 16384, 2048
+    mb = N // n_mb
     ug = m._build_update_graph(mb)
     for trial in range(6):
         idx = torch.randperm(N, device="cuda")[:mb]
