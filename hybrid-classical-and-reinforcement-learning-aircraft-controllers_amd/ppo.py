@@ -149,7 +149,9 @@ class RecurrentPPO:
         self.policy = (policy or RateLSTMPolicy()).to(self.device)
         broadcast_parameters(self.policy)
         self.flat = FlatGrad(self.policy)
-        self.opt = torch.optim.Adam(self.policy.parameters(), lr=self.cfg.learning_rate, eps=1e-5)
+        # one fused multi-tensor kernel per optimizer step on the GPU (the foreach form is a dozen launches over 33 tensors)
+        self.opt = torch.optim.Adam(self.policy.parameters(), lr=self.cfg.learning_rate, eps=1e-5,
+                                    **({"fused": True} if self.device.type == "cuda" else {}))
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
         torch.manual_seed(seed + 7919 * (rank + 1))      # different exploration noise per rank
         N, T = env.num_envs, self.cfg.n_steps
