@@ -89,6 +89,9 @@ def parse():
     ap.add_argument("--policy-dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU-side rendezvous for rehearsals")
     ap.add_argument("--device-index", type=int, default=-1, help="force every rank onto this GPU (1-GPU rehearsal of N>1)")
+    ap.add_argument("--single-rank-group", action="store_true",
+                    help="N = 1 only: still create the process group (one rank) and run the N > 1 line's train leg with its "
+                         "all-reduce -- the rehearsal of the RCCL calls that a one-GPU box allows")
     ap.add_argument("--physics-substeps", type=int, default=1,
                     help="physics workload: RK4 sub-steps of 1 ms fused per launch (1 = Simplified6DOF.step(0.01); 20 = the env's backend step)")
     ap.add_argument("--ppo-steps", type=int, default=16, help="rollout length per PPO iteration (train workload)")
@@ -108,13 +111,23 @@ def setup_dist(args):
                          f"--nproc-per-node {args.gpus} bench.py --gpus {args.gpus}`")
     dev = args.device_index if args.device_index >= 0 else local
     torch.cuda.set_device(dev)
-    if world > 1:
+    if world > 1 or args.single_rank_group:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ["HCRL_FORCE_COLLECTIVE"] = "1"         # ppo.FlatGrad: issue the all-reduce in a one-rank group too
+        # a rank that dies leaves the others in a collective: bound the wait (the default is 10 minutes per call)
+        tmo = datetime.timedelta(seconds=240)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev), timeout=tmo)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=tmo)
     return world, rank, local
 
 
@@ -273,19 +286,24 @@ class StepLoop:
         return ("hipGraph x%d" % self.gsteps) if self.graphs else "eager"
 
 
+def _grouped():
+    return torch.distributed.is_available() and torch.distributed.is_initialized()
+
+
 def timed_region(wl, args, world, min_region_s=0.05, max_repeats=31):
     """W warm-up steps, then EXACTLY K timed steps bracketed by barrier + synchronize; HIP events on the launch stream.
     When the K-step region is shorter than `min_region_s` (K = 20 launches of 68 us is 1.4 ms: two timer reads and a
     launch-queue hiccup are a tenth of it) the same K-step region is timed R times and the MEDIAN is reported
     (`repeats` in the output); K itself never changes."""
     K, W = args.steps, args.warmup
+    grp = world > 1 or (getattr(args, "single_rank_group", False) and _grouped())
     stream = torch.cuda.current_stream()
     loop = StepLoop(wl, args)
     loop.run(W)
 
     def once():
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        if world > 1:
+        if grp:
             torch.distributed.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -293,11 +311,11 @@ def timed_region(wl, args, world, min_region_s=0.05, max_repeats=31):
         loop.run(K)
         ev1.record(stream)
         torch.cuda.synchronize()
-        if world > 1:
+        if grp:
             torch.distributed.barrier()
         wall = time.perf_counter() - t0
         dev_ms = ev0.elapsed_time(ev1)
-        if world > 1:
+        if grp:
             t = torch.tensor([wall], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             wall = float(t.item())
@@ -307,7 +325,7 @@ def timed_region(wl, args, world, min_region_s=0.05, max_repeats=31):
     repeats = 1
     if samples[0][0] < min_region_s:
         repeats = int(min(max_repeats, max(3, (0.25 / max(samples[0][0], 1e-6)))) // 2 * 2 + 1)      # odd
-        if world > 1:                                              # every rank must take the same number of barriers
+        if grp:                                              # every rank must take the same number of barriers
             t = torch.tensor([repeats], dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
             torch.distributed.broadcast(t, 0)
             repeats = int(t.item())
@@ -324,6 +342,7 @@ def train_leg(args, rank, world):
     import copy
     a = copy.copy(args)
     a.workload = "train"
+    grp = world > 1 or (getattr(args, "single_rank_group", False) and _grouped())
     wl = Workload(a, rank)
     flat = wl.ppo.flat
     iters, warm = 3, 1
@@ -331,19 +350,19 @@ def train_leg(args, rank, world):
         wl.step(k)
     torch.cuda.synchronize()
     flat.events = []
-    if world > 1:
+    if grp:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(iters):
         wl.step(k)
     torch.cuda.synchronize()
-    if world > 1:
+    if grp:
         torch.distributed.barrier()
     wall = time.perf_counter() - t0
     ar_ms = [e0.elapsed_time(e1) for e0, e1 in flat.events]
     flat.events = None
-    if world > 1:
+    if grp:
         t = torch.tensor([wall], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         wall = float(t.item())
@@ -351,7 +370,7 @@ def train_leg(args, rank, world):
     res = {"value": wl.units_per_step * iters * world / wall, "unit": "env-steps/s", "ms_per_iteration": wall * 1e3 / iters,
            "iterations": iters, "workload": wl.desc, "optimizer_steps_per_iteration": opt_steps,
            "policy": policy_block(wl, a, wall / iters, "train")}
-    if world > 1:
+    if grp:
         res["collective"] = {"op": "all_reduce(sum) of the flat fp32 gradient buffer", "backend": args.backend,
                              "library": "RCCL over xGMI" if args.backend == "nccl" else "gloo (CPU rehearsal)",
                              "n_ranks_in_group": torch.distributed.get_world_size(), "bytes": int(flat.buf.numel() * 4),
@@ -549,8 +568,13 @@ def main():
     del wl
     torch.cuda.empty_cache()
     train = None
-    if world > 1 and args.workload == "env" and not args.no_extras:
-        train = train_leg(args, rank, world)                      # every rank: it contains the collective
+    if (world > 1 or args.single_rank_group) and args.workload == "env" and not args.no_extras:
+        # every rank runs it: it contains the collective.  A failure must not cost the headline line (a deterministic error
+        # reaches every rank alike; a rank lost inside a collective ends the others at the process group's timeout)
+        try:
+            train = train_leg(args, rank, world)
+        except Exception as ex:
+            train = {"error": repr(ex)}
     if rank != 0:
         return
     per_launch_s = dev_ms * 1e-3 / K
@@ -595,7 +619,7 @@ def main():
         out["policy"] = pol
     if train is not None:
         out["train"] = train
-    if world == 1 and args.workload == "env" and not args.no_extras:
+    if world == 1 and args.workload == "env" and not args.no_extras and not args.single_rank_group:
         out["extras"] = extras(args)
     if world == 1 and not args.no_cpu_baseline:
         try:
@@ -608,5 +632,5 @@ def main():
 
 if __name__ == "__main__":
     main()
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

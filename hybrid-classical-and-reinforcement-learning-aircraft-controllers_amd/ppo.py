@@ -14,6 +14,7 @@ MI355X-first choices:
     `all_reduce` of ~7.3 MB per optimizer step on RCCL/xGMI -- latency-bound, hence one call instead of per-tensor
     buckets; envs never communicate.
 """
+import os
 import time
 from dataclasses import dataclass
 from typing import Optional
@@ -71,7 +72,9 @@ class FlatGrad:
         self.buf.zero_()
 
     def all_reduce_mean(self):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # HCRL_FORCE_COLLECTIVE: a one-rank group still issues the call (bench.py --single-rank-group: the only rehearsal of
+        # the RCCL path a one-GPU box allows)
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("HCRL_FORCE_COLLECTIVE") == "1"):
             timed = self.events is not None and self.buf.is_cuda
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -58,6 +58,18 @@ __global__ void __launch_bounds__(512) k(float* out, uint64_t* cyc)
                 asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n"
                              "v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));
+            } else if (MODE == 10) {  // 8 independent v_mul_f32 in the 4-byte VOP2 encoding (the env step's hot loop is half e32 forms)
+                asm volatile("v_mul_f32_e32 %0, %8, %0\n v_mul_f32_e32 %1, %8, %1\n v_mul_f32_e32 %2, %8, %2\n v_mul_f32_e32 %3, %8, %3\n"
+                             "v_mul_f32_e32 %4, %8, %4\n v_mul_f32_e32 %5, %8, %5\n v_mul_f32_e32 %6, %8, %6\n v_mul_f32_e32 %7, %8, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            } else if (MODE == 11) {  // 8 independent v_fmac_f32 (VOP2, 4 bytes)
+                asm volatile("v_fmac_f32_e32 %0, %8, %9\n v_fmac_f32_e32 %1, %8, %9\n v_fmac_f32_e32 %2, %8, %9\n v_fmac_f32_e32 %3, %8, %9\n"
+                             "v_fmac_f32_e32 %4, %8, %9\n v_fmac_f32_e32 %5, %8, %9\n v_fmac_f32_e32 %6, %8, %9\n v_fmac_f32_e32 %7, %8, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            } else if (MODE == 12) {  // v_fmaak_f32 (VOP2 + 32-bit literal, 8 bytes)
+                asm volatile("v_fmaak_f32 %0, %8, %0, 0x3a83126f\n v_fmaak_f32 %1, %8, %1, 0x3a83126f\n v_fmaak_f32 %2, %8, %2, 0x3a83126f\n v_fmaak_f32 %3, %8, %3, 0x3a83126f\n"
+                             "v_fmaak_f32 %4, %8, %4, 0x3a83126f\n v_fmaak_f32 %5, %8, %5, 0x3a83126f\n v_fmaak_f32 %6, %8, %6, 0x3a83126f\n v_fmaak_f32 %7, %8, %7, 0x3a83126f\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
             } else if (MODE == 9) {   // v_med3_f32 + v_cndmask mix: 8 independent v_med3
                 asm volatile("v_med3_f32 %0, %0, %8, %9\n v_med3_f32 %1, %1, %8, %9\n v_med3_f32 %2, %2, %8, %9\n v_med3_f32 %3, %3, %8, %9\n"
                              "v_med3_f32 %4, %4, %8, %9\n v_med3_f32 %5, %5, %8, %9\n v_med3_f32 %6, %6, %8, %9\n v_med3_f32 %7, %7, %8, %9\n"
@@ -104,6 +116,9 @@ int main()
         run<6>("8 independent v_rcp_f32", t, out, cyc, h);
         run<7>("2 interleaved dependent v_fma_f64 chains", t, out, cyc, h);
         run<9>("8 independent v_med3_f32", t, out, cyc, h);
+        run<10>("8 independent v_mul_f32_e32 (4-byte)", t, out, cyc, h);
+        run<11>("8 independent v_fmac_f32_e32 (4-byte)", t, out, cyc, h);
+        run<12>("8 independent v_fmaak_f32 (4 + 4 bytes)", t, out, cyc, h);
     }
     return 0;
 }

@@ -42,3 +42,14 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", *COMMON], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, env=env, timeout=600)
     assert p.returncode != 0 and b"WORLD_SIZE=1" in p.stderr and p.stdout.strip() == b""
+
+
+def test_bench_single_rank_group_runs_the_train_leg_on_rccl():
+    """The RCCL calls of the N > 1 line on the one GPU this box has: a ONE-rank `nccl` process group (communicator init,
+    barriers, the MAX all-reduce of the timing, the flat 7.3 MB gradient all-reduce between the update graphs), with the
+    hipGraph captures running beside the process group's watchdog thread."""
+    one = _bench("--gpus", "1", "--backend", "nccl", "--single-rank-group")
+    assert one["n_gpus"] == 1 and "error" not in one["train"], one["train"]
+    col = one["train"]["collective"]
+    assert col["backend"] == "nccl" and col["n_ranks_in_group"] == 1 and col["bytes"] == 1830089 * 4
+    assert col["calls_timed"] == 3 * one["train"]["optimizer_steps_per_iteration"] and col["allreduce_us_per_optimizer_step"] > 0
