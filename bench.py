@@ -406,8 +406,8 @@ def measured_drift(precision):
     d = json.load(open(dpath)).get(precision)
     if not d:
         return None
-    keep = ("p50", "p90", "p99", "max", "n", "n_regular", "max_regular", "n_over_1e-4", "fp32_argument_model_p50",
-            "flag_mismatch_envs", "max_where_d7_le_1e5")
+    keep = ("p50", "p90", "p99", "p99.9", "max", "n", "n_regular", "max_regular", "n_over_1e-4", "n_over_gate",
+            "fp32_argument_model_p50", "flag_mismatch_envs", "max_where_d7_le_1e5")
     return {k: {q: v[q] for q in keep if q in v} for k, v in d.items() if isinstance(v, dict)}
 
 
