@@ -80,16 +80,37 @@ FD_DEV void sincos(float x, float& s, float& c)
 // The two polynomial chains run as the halves of v_pk_fma_f32 (gfx950 packed fp32: two FMAs per instruction, and at one wave
 // per SIMD an instruction is ~5 cycles whatever it does): 4 + 2 instructions per rotation instead of 6 + 2; same values.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-FD_DEV void rotate_small(float s, float c, float d, float& so, float& co)
+FD_DEV f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+FD_DEV f32x2 bc(float x) { return (f32x2){ x, x }; }
+// (x, undefined): an operand of which the packed instruction reads the LOW half for both results -- no copy to build (x, x)
+FD_DEV f32x2 lo_only(float x) { f32x2 r; r.x = x; return r; }      // r.y deliberately unset: (x, x) would cost a v_mov
+// A plane rotation negates ONE half of a pair.  The hardware has the per-half modifier (neg_lo / neg_hi); LLVM does not select
+// it for packed fp32 (it emits v_pk_add_f32 x, 0 neg + v_mov: two instructions per negated half), so the two forms a rotation
+// needs are spelled as ONE instruction each.  Their operands come from plain VALU instructions only (FMAs and products), never
+// straight from a transcendental: the compiler does not see into the assembly to insert that wait state.
+//   a * b.xx + (c.x, -c.y)
+FD_DEV f32x2 pk_fma_bx_nhi(f32x2 a, f32x2 b, f32x2 c)
+{
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+//   a.yx * b.xx + (-c.x, c.y)
+FD_DEV f32x2 pk_fma_ayx_bx_nlo(f32x2 a, f32x2 b, f32x2 c)
+{
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[0,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// rotate sc = (sin a, cos a) by a SMALL angle d: (s cd + c sd, c cd - s sd), the products and FMAs of the scalar form
+// (so = fma(s, cd, c sd), co = fma(c, cd, -(s sd))) as one packed product + one packed FMA: 6 instructions per rotation
+FD_DEV f32x2 rotate_small(f32x2 sc, float d)
 {
     const float z = d * d;
-    const f32x2 zz = { z, z };
-    const f32x2 p1 = __builtin_elementwise_fma(zz, (f32x2){ 4.1666667908e-2f, 8.3333337680e-3f }, (f32x2){ -0.5f, -1.6666667163e-1f });
-    const f32x2 p2 = __builtin_elementwise_fma(zz, p1, (f32x2){ 1.0f, 0.0f });       // (cos d, (sin d - d) / d)
-    const float cd = p2.x;
+    const f32x2 p1 = pk_fma(bc(z), (f32x2){ 4.1666667908e-2f, 8.3333337680e-3f }, (f32x2){ -0.5f, -1.6666667163e-1f });
+    const f32x2 p2 = pk_fma(bc(z), p1, (f32x2){ 1.0f, 0.0f });       // (cos d, (sin d - d) / d)
     const float sd = __builtin_fmaf(p2.y, d, d);
-    so = __builtin_fmaf(s, cd, c * sd);
-    co = __builtin_fmaf(c, cd, -(s * sd));
+    return pk_fma_bx_nhi(sc, p2, sc.yx * bc(sd));
 }
 // cos(x): Taylor to x^8 while |x| <= 0.8 rad (truncation < 3e-8; a bank command is limited to 25 deg), full reduction beyond
 FD_DEV float cos_bounded(float x)
@@ -141,6 +162,21 @@ FD_DEV float asin_wide_t(float t, float z)
     p = __builtin_fmaf(z, p, 7.5183674693e-02f);
     p = __builtin_fmaf(z, p, 1.6666238010e-01f);
     return __builtin_fmaf(p * z, t, t);
+}
+// atan_wide(ta) and asin_wide_t(tb, zb) in one go: (atan(ta), asin-polynomial(tb, zb)); every FMA is the one the two scalar
+// functions make, the last four Horner steps, the p z product and the closing FMA two per v_pk_* instruction
+FD_DEV f32x2 atan_asin_wide(float ta, float za, float tb, float zb)
+{
+    const float pa = __builtin_fmaf(za, 2.0541535690e-02f, -6.1546623707e-02f);
+    float pb = __builtin_fmaf(zb, 2.1202674508e-01f, -3.1944271922e-01f);
+    pb = __builtin_fmaf(zb, pb, 2.6334178448e-01f);
+    pb = __builtin_fmaf(zb, pb, -7.6388612390e-02f);
+    const f32x2 z = { za, zb }, t = { ta, tb };
+    f32x2 p = pk_fma(z, (f32x2){ pa, pb }, (f32x2){ 1.0221967846e-01f, 5.3024884313e-02f });
+    p = pk_fma(z, p, (f32x2){ -1.4136675000e-01f, 4.1755288839e-02f });
+    p = pk_fma(z, p, (f32x2){ 1.9987617433e-01f, 7.5183674693e-02f });
+    p = pk_fma(z, p, (f32x2){ -3.3332955837e-01f, 1.6666238010e-01f });
+    return pk_fma(p * z, t, t);
 }
 FD_DEV float atan_pos(float a)
 {   // atan for a >= 0 (Cephes atanf: two range reductions + degree-4 polynomial in a^2), branch-free
@@ -260,6 +296,10 @@ template <typename T> struct Params {
     T inv_ixx, inv_iyy, inv_izz, sin_max_alpha, cos_max_alpha;
     T half_b, half_c, inv_thrust_zero_v, izz_m_iyy, ixx_m_izz, iyy_m_ixx, half_rho_S, tan_alpha_fast, alpha_needs_atan2,
       sin_max_pitch, cos_max_pitch;   // fp32 evaluation only
+    // fp32 evaluation only: the constants the packed roll / yaw moment build-up multiplies by, as the pairs it reads them in
+    // (whole members: pairs assembled at the use site from adjacent scalar members made the compiler keep a slice of this
+    // struct in scratch)
+    fast::f32x2 pk_b_c, pk_half_b_c, pk_damp_pr, pk_beta_ln, pk_inv_i_pr;
 
     // `blk` points at one FD_NP-word block staged in LDS (stored as double; narrowed here once per launch)
     FD_DEV void load(const double* blk)
@@ -286,6 +326,14 @@ template <typename T> struct Params {
         half_rho_S = half_rho * S; tan_alpha_fast = T(blk[FD_PD_TAN_ALPHA_FAST]);
         alpha_needs_atan2 = T(blk[FD_PD_ALPHA_NEEDS_ATAN2]);
         sin_max_pitch = T(blk[FD_PD_SIN_MAX_PITCH]); cos_max_pitch = T(blk[FD_PD_COS_MAX_PITCH]);
+        if constexpr (sizeof(T) == 4) {
+            const float b_ = float(blk[FD_P_WING_SPAN]), c_ = float(blk[FD_P_CHORD]);
+            pk_b_c = (fast::f32x2){ b_, c_ };
+            pk_half_b_c = (fast::f32x2){ 0.5f * b_, 0.5f * c_ };
+            pk_damp_pr = (fast::f32x2){ float(blk[FD_P_DAMPING_ROLL]), float(blk[FD_P_DAMPING_YAW]) };
+            pk_beta_ln = (fast::f32x2){ float(blk[FD_P_CL_BETA]), float(blk[FD_P_CN_BETA]) };
+            pk_inv_i_pr = (fast::f32x2){ float(blk[FD_PD_INV_IXX]), float(blk[FD_PD_INV_IZZ]) };
+        }
     }
     // The derived words exist only in the STAGED (LDS) copy of a parameter block (stride FD_NP_STAGED): the first
     // FD_ND_LANES threads of a workgroup fill them while the block is staged (fdyn_kernels.hip: stage_params), one word per
@@ -337,6 +385,7 @@ template <typename T> struct Controls {
     T de_rad, da_rad, dr_rad, throttle;
     // fp32 evaluation only: the control-dependent terms of the coefficient build-up, constant over a launch's sub-steps
     T cl0_de, cm_de, cl_da, cn_dr, cy, thrust_max;
+    fast::f32x2 pk_da_dr;                                               // (cl_da, cn_dr) as the pair the moment build-up reads
     template <typename S> FD_DEV void set(const Params<T>& P, S elevator, S aileron, S rudder, S thr)
     {
         de_rad = T(clipv<S>(elevator, S(-1), S(1))) * P.max_de;     // :383
@@ -348,6 +397,7 @@ template <typename T> struct Controls {
             cm_de = P.cm_de * de_rad;                               // :424
             cl_da = P.cl_da * da_rad;                               // :419
             cn_dr = P.cn_dr * dr_rad;                               // :431
+            pk_da_dr = (fast::f32x2){ P.cl_da * da_rad, P.cn_dr * dr_rad };
             cy = P.cy_dr * dr_rad;                                  // :390
             thrust_max = P.max_thrust * throttle;                   // :404
         }
@@ -451,21 +501,30 @@ FD_DEV void dynamics(const Params<T>& P, const Controls<T>& C, const T (&x)[FD_N
 //     V >= min_airspeed, |u_safe| >= min_u, |cos theta_safe| >= cos(max_pitch)), and the state is re-checked after every
 //     step by rk4_substeps' combined predicate -- the reference's guard (:496-501) can only fire on a non-finite state,
 //     which its own step() (:286-291) never leaves behind either.
-struct Trig { float sphi, cphi, sth, cth, spsi, cpsi; };
+struct Trig { fast::f32x2 phi, th, psi; };          // (sin, cos) of roll, pitch, yaw as packed pairs (v_pk_* operands)
 FD_DEV Trig trig_of(float phi, float theta, float psi)
 {
     Trig t;
-    fast::sincos(phi, t.sphi, t.cphi); fast::sincos(theta, t.sth, t.cth); fast::sincos(psi, t.spsi, t.cpsi);
+    float s, c;
+    fast::sincos(phi, s, c); t.phi = (fast::f32x2){ s, c };
+    fast::sincos(theta, s, c); t.th = (fast::f32x2){ s, c };
+    fast::sincos(psi, s, c); t.psi = (fast::f32x2){ s, c };
     return t;
 }
 // rotate by (d_phi, d_theta, d_psi); returns max |d|: beyond 0.125 rad the series is not good enough and the next
 // dynamics_fast call re-evaluates the sincos in full (its `dmax` argument)
 FD_DEV float trig_rotate(const Trig& t0, float dphi, float dth, float dpsi, Trig& t)
 {
-    fast::rotate_small(t0.sphi, t0.cphi, dphi, t.sphi, t.cphi);
-    fast::rotate_small(t0.sth, t0.cth, dth, t.sth, t.cth);
-    fast::rotate_small(t0.spsi, t0.cpsi, dpsi, t.spsi, t.cpsi);
+    t.phi = fast::rotate_small(t0.phi, dphi);
+    t.th = fast::rotate_small(t0.th, dth);
+    t.psi = fast::rotate_small(t0.psi, dpsi);
     return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(dphi), __builtin_fabsf(dth)), __builtin_fabsf(dpsi));
+}
+// the same with the increments h * (k_phi, k_theta), h * k_psi formed here (the first two as one packed product)
+FD_DEV float trig_rotate_scaled(const Trig& t0, float h, float kphi, float kth, float kpsi, Trig& t)
+{
+    const fast::f32x2 d2 = fast::bc(h) * (fast::f32x2){ kphi, kth };
+    return trig_rotate(t0, d2.x, d2.y, h * kpsi, t);
 }
 
 #define FD_UNLIKELY(c) __builtin_expect(!!(c), 0)
@@ -497,7 +556,9 @@ FD_DEV void dynamics_fast(const Params<float>& P, const Controls<float>& C, cons
     const float u = x[3], v = x[4], w = x[5], theta = x[7];
     const float p = x[9], q = x[10], r = x[11];
 
-    const float uw2 = __builtin_fmaf(u, u, w * w);
+    const fast::f32x2 vw = { v, w };
+    const fast::f32x2 vw_sq = vw * vw;                                                      // v^2, w^2
+    const float uw2 = __builtin_fmaf(u, u, vw_sq.y);
     const float V2 = __builtin_fmaf(v, v, uw2);
     const float airspeed = fast::sqrt(V2);                                                  // :363
     const float Vs = fast::max_nc(airspeed, P.min_airspeed);                                // :364
@@ -510,11 +571,11 @@ FD_DEV void dynamics_fast(const Params<float>& P, const Controls<float>& C, cons
     const float au = __builtin_fabsf(u);
     const float au_min = fast::max_nc(au, P.min_u);
     const float us = au > 1e-6f ? __builtin_copysignf(au_min, u) : P.min_u;
-    const float inv_h = fast::rsq(__builtin_fmaf(us, us, w * w));                           // |u_safe| >= min_u > 0
-    const float t_alpha = w * fast::rcp(us);
+    const float inv_h = fast::rsq(__builtin_fmaf(us, us, vw_sq.y));                         // |u_safe| >= min_u > 0
+    const fast::f32x2 xt_ab = vw * (fast::f32x2){ inv_V, fast::rcp(us) };                   // v / V, w / u_safe
+    const fast::f32x2 xt_sq = xt_ab * xt_ab;
+    const float t_alpha = xt_ab.y;
     const bool a_in = __builtin_fabsf(w) <= P.tan_alpha_fast * us;
-    const float alpha_poly = fast::pinned(fast::atan_wide(t_alpha));
-    const float alpha = a_in ? alpha_poly : __builtin_copysignf(P.max_alpha, w);
     const float sin_alpha = a_in ? w * inv_h : __builtin_copysignf(P.sin_max_alpha, w);
     const float cos_alpha = a_in ? us * inv_h : P.cos_max_alpha;
 
@@ -527,28 +588,34 @@ FD_DEV void dynamics_fast(const Params<float>& P, const Controls<float>& C, cons
     // step (113 k cycles for the RK4 phase against 72 k, scratch/phase_stamps.py) and the launch waited for those waves.
     const float av = __builtin_fabsf(v);
     const bool b_in = av <= FD_ASIN_WIDE_LIMIT * Vs;
-    const float xb = v * inv_V;
+    const float xb = xt_ab.x;
     auto beta_tail = [&]() {                                 // |v| / V beyond 0.75
         const float vv_rest = airspeed >= P.min_airspeed ? uw2 : __builtin_fmaxf(__builtin_fmaf(Vs, Vs, -(v * v)), 0.0f);   // V^2 - v^2 (V clamped: :364)
         const float half_om = 0.5f * (vv_rest * fast::rcp(Vs * (Vs + av)));                 // (1 - |v| / V) / 2 <= 0.125
         const float b_r = fast::asin_wide_t(fast::sqrt(half_om), half_om);
         return __builtin_copysignf(__builtin_fmaf(-2.0f, b_r, 1.5707963267948966f), v);
     };
-    float beta;
+    // atan_wide(t_alpha) and asin_wide_t(b_t, z_b) -- the two no-range-reduction polynomials -- share their last four Horner
+    // steps, the p z product and the final FMA as packed instructions (the same FMAs, two per instruction)
+    float beta, b_t, z_b;
     if constexpr (STRAIGHT) {
-        const float vv_rest = airspeed >= P.min_airspeed ? uw2 : __builtin_fmaxf(__builtin_fmaf(Vs, Vs, -(v * v)), 0.0f);
+        const float vv_rest = airspeed >= P.min_airspeed ? uw2 : __builtin_fmaxf(__builtin_fmaf(Vs, Vs, -vw_sq.x), 0.0f);
         const float half_om = 0.5f * (vv_rest * fast::rcp(Vs * (Vs + av)));
-        const float b_t = b_in ? xb : fast::sqrt(half_om);
-        const float b_r = fast::asin_wide_t(b_t, b_in ? xb * xb : half_om);
-        beta = b_in ? b_r : __builtin_copysignf(__builtin_fmaf(-2.0f, b_r, 1.5707963267948966f), v);
+        b_t = b_in ? xb : fast::sqrt(half_om);
+        z_b = b_in ? xt_sq.x : half_om;
     } else {
-        beta = fast::asin_wide_t(xb, xb * xb);              // the tail is fixed up in the rare block below
+        b_t = xb; z_b = xt_sq.x;                            // the tail is fixed up in the rare block below
     }
+    const fast::f32x2 ab = fast::atan_asin_wide(t_alpha, xt_sq.y, b_t, z_b);
+    const float alpha_poly = fast::pinned(ab.x);
+    const float alpha = a_in ? alpha_poly : __builtin_copysignf(P.max_alpha, w);
+    if constexpr (STRAIGHT) beta = b_in ? ab.y : __builtin_copysignf(__builtin_fmaf(-2.0f, ab.y, 1.5707963267948966f), v);
+    else beta = ab.y;
 
     // ---- clamped pitch for the Euler rates :463: sin / cos of clip(theta) are the carried ones or those of +-max_pitch
     const bool th_in = __builtin_fabsf(theta) <= P.max_pitch;
-    float sth_e = th_in ? tg.sth : __builtin_copysignf(P.sin_max_pitch, theta);
-    float cth_e = th_in ? tg.cth : P.cos_max_pitch;
+    float sth_e = th_in ? tg.th.x : __builtin_copysignf(P.sin_max_pitch, theta);
+    float cth_e = th_in ? tg.th.y : P.cos_max_pitch;
 
     // ---- the rare block: an Euler-angle increment too large for the rotation series (after a wrap / pitch clamp, or 10 ms steps
     // of a tumbling aircraft), or an aircraft type whose alpha limit lies beyond the polynomial -- transient or absent
@@ -559,7 +626,7 @@ FD_DEV void dynamics_fast(const Params<float>& P, const Controls<float>& C, cons
         if (!(dmax <= 0.125f)) {
             FD_DBG_COUNT1(4)
             tg = trig_of(x[6], theta, x[8]);
-            sth_e = th_in ? tg.sth : sth_e; cth_e = th_in ? tg.cth : cth_e;
+            sth_e = th_in ? tg.th.x : sth_e; cth_e = th_in ? tg.th.y : cth_e;
         }
         if (P.alpha_needs_atan2 != 0.0f) {                  // max_alpha > 35 deg: the reference's own sequence
             const float a_raw = fast::atan2(w, us);
@@ -572,44 +639,57 @@ FD_DEV void dynamics_fast(const Params<float>& P, const Controls<float>& C, cons
             if (!b_in) beta = beta_tail();
         }
     }
-    const float sphi = tg.sphi, cphi = tg.cphi, cpsi = tg.cpsi, spsi = tg.spsi, sth = tg.sth, cth = tg.cth;
+    const float sth = tg.th.x, cth = tg.th.y;
 
+    using fast::f32x2;
+    using fast::bc;
     const float q_S = P.half_rho_S * V2;                                                    // :379 (unclamped V)
     const float cl = __builtin_fmaf(P.cl_alpha, alpha_r, C.cl0_de);                           // :384-390
     const float cd = __builtin_fmaf(P.cd_alpha2, alpha_r * alpha_r, P.cd_0);
-    const float lift = q_S * cl, drag = q_S * cd;
-    const float fx_aero = __builtin_fmaf(lift, sin_alpha_r, -(drag * cos_alpha_r));             // :397-399
-    const float fz_aero = -__builtin_fmaf(lift, cos_alpha_r, drag * sin_alpha_r);
+    const f32x2 ld = bc(q_S) * (f32x2){ cl, cd };                                           // lift, drag
+    // :397-399  (fx, -fz) = (lift sin - drag cos, lift cos + drag sin): a plane rotation, one packed product + one packed FMA
+    const f32x2 cs_a = { cos_alpha_r, sin_alpha_r };
+    const f32x2 fxz = fast::pk_fma_ayx_bx_nlo(cs_a, ld, ld.yy * cs_a);
     const float thrust = C.thrust_max * __builtin_fmaxf(0.0f, __builtin_fmaf(-airspeed, P.inv_thrust_zero_v, 1.0f));   // :403
 
     // :409-411 + :455-460   a = F/m + g-terms - omega x v
-    xd[3] = __builtin_fmaf(fx_aero + thrust, P.inv_mass, __builtin_fmaf(r, v, __builtin_fmaf(-q, w, -(P.g * sth))));
-    xd[4] = __builtin_fmaf(q_S * C.cy, P.inv_mass, __builtin_fmaf(p, w, __builtin_fmaf(-r, u, P.g * (cth * sphi))));
-    xd[5] = __builtin_fmaf(fz_aero, P.inv_mass, __builtin_fmaf(q, u, __builtin_fmaf(-p, v, P.g * (cth * cphi))));
+    const f32x2 g_cs = bc(P.g) * (tg.phi * bc(cth));                                        // g (cth sphi), g (cth cphi)
+    xd[3] = __builtin_fmaf(fxz.x + thrust, P.inv_mass, __builtin_fmaf(r, v, __builtin_fmaf(-q, w, -(P.g * sth))));
+    xd[4] = __builtin_fmaf(q_S * C.cy, P.inv_mass, __builtin_fmaf(p, w, __builtin_fmaf(-r, u, g_cs.x)));
+    xd[5] = __builtin_fmaf(-fxz.y, P.inv_mass, __builtin_fmaf(q, u, __builtin_fmaf(-p, v, g_cs.y)));
 
-    const float hsV = P.half_b * inv_V, hcV = P.half_c * inv_V;                             // :416-417
-    const float qSb = q_S * P.b;
-    const float l_moment = qSb * __builtin_fmaf(P.cl_beta, beta, __builtin_fmaf(P.damp_roll * p, hsV, C.cl_da));
-    const float m_moment = (q_S * P.c) * __builtin_fmaf(P.cm_alpha, alpha_r, __builtin_fmaf(P.damp_pitch * q, hcV, C.cm_de));
-    const float n_moment = qSb * __builtin_fmaf(P.cn_beta, beta, __builtin_fmaf(P.damp_yaw * r, hsV, C.cn_dr));
-    xd[9] = __builtin_fmaf(-P.izz_m_iyy * q, r, l_moment) * P.inv_ixx;                      // :474-482
+    // :416-431, :474-482  roll and yaw moments have one shape: packed as (l, n)
+    const f32x2 hV = P.pk_half_b_c * bc(inv_V);                             // :416-417
+    const f32x2 qSbc = bc(q_S) * P.pk_b_c;
+    const f32x2 pr = { p, r };
+    const f32x2 ln_in = fast::pk_fma(P.pk_damp_pr * pr, bc(hV.x), C.pk_da_dr);
+    const f32x2 ln = bc(qSbc.x) * fast::pk_fma(P.pk_beta_ln, bc(beta), ln_in);
+    const float m_moment = qSbc.y * __builtin_fmaf(P.cm_alpha, alpha_r, __builtin_fmaf(P.damp_pitch * q, hV.y, C.cm_de));
+    const f32x2 gy = { __builtin_fmaf(-P.izz_m_iyy * q, r, ln.x), __builtin_fmaf(-P.iyy_m_ixx * p, q, ln.y) };
+    const f32x2 a_pr = gy * P.pk_inv_i_pr;                                // :474-482
+    xd[9] = a_pr.x;
     xd[10] = __builtin_fmaf(-P.ixx_m_izz * p, r, m_moment) * P.inv_iyy;
-    xd[11] = __builtin_fmaf(-P.iyy_m_ixx * p, q, n_moment) * P.inv_izz;
+    xd[11] = a_pr.y;
 
     // :440-452 NED rates: Rz(psi) * [ (cth u + sth (sphi v + cphi w)), (cphi v - sphi w) ],  down = cth (sphi v + cphi w) - sth u
-    const float sv_cw = __builtin_fmaf(sphi, v, cphi * w);
+    // the plane rotations as packed pairs (the scalar form's products and FMAs, two per instruction):
+    // (sv_cw, bh) = (sphi v + cphi w, cphi v - sphi w)
+    const fast::f32x2 sb = fast::pk_fma_bx_nhi(tg.phi, fast::lo_only(v), tg.phi.yx * fast::bc(w));
+    const float sv_cw = sb.x;
     const float ah = __builtin_fmaf(cth, u, sth * sv_cw);
-    const float bh = __builtin_fmaf(cphi, v, -(sphi * w));
-    xd[0] = __builtin_fmaf(cpsi, ah, -(spsi * bh));
-    xd[1] = __builtin_fmaf(spsi, ah, cpsi * bh);
+    // (north, east) = (cpsi ah - spsi bh, spsi ah + cpsi bh)
+    const fast::f32x2 ne = fast::pk_fma_ayx_bx_nlo(tg.psi, fast::lo_only(ah), tg.psi * fast::bc(sb.y));
+    xd[0] = ne.x;
+    xd[1] = ne.y;
     xd[2] = __builtin_fmaf(cth, sv_cw, -(sth * u));
 
-    // :463-471 Euler rates with the clamped pitch
+    // :463-471 Euler rates with the clamped pitch:  (qr, theta_dot) = (sphi q + cphi r, cphi q - sphi r)
     const float inv_c = fast::rcp(cth_e);
-    const float qr = __builtin_fmaf(sphi, q, cphi * r);
+    const fast::f32x2 qt = fast::pk_fma_bx_nhi(tg.phi, fast::lo_only(q), tg.phi.yx * fast::bc(r));
+    const float qr = qt.x;
     xd[8] = qr * inv_c;
     xd[6] = __builtin_fmaf(sth_e * inv_c, qr, p);
-    xd[7] = __builtin_fmaf(cphi, q, -(sphi * r));
+    xd[7] = qt.y;
 
 #pragma unroll
     for (int i = 9; i < 12; ++i) xd[i] = clipf(xd[i], -P.max_ang_acc, P.max_ang_acc);      // :485-490
@@ -690,34 +770,50 @@ FD_DEV void rk4_fast_step(const Params<float>& P, const Limits<S>& Lm, const Con
     using T = float;
     // position (0..2) feeds nothing back, and roll / yaw enter only through their sin / cos: the stage states carry velocity,
     // angles (for the rare full rebuild and the +-85 deg guard) and rates; the trigonometry is rotated
-    T xt[FD_NX], k[FD_NX], acc[FD_NX];
+    T xt[FD_NX], k[FD_NX];
     Trig tt;
+    // the stage combinations as packed pairs (words PA[j], PB[j]): acc += w k and xt = x0 + h k are two FMAs per instruction.
+    // (Pairing (8,10) (9,11), so that (p, r) -- the pair the roll / yaw moment build-up reads and writes -- passes through
+    // whole, measured four instructions MORE per sub-step than the plain order: the storage-type accumulate hands the words
+    // back one by one either way.)
+    using fast::f32x2;
+    constexpr int PA[6] = { 0, 2, 4, 6, 8, 10 }, PB[6] = { 1, 3, 5, 7, 9, 11 };
+    f32x2 acc2[6], x02[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) x02[j] = (f32x2){ f.x0[PA[j]], f.x0[PB[j]] };
+    auto stage = [&](T h, T wgt, bool first) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const f32x2 kj = { k[PA[j]], k[PB[j]] };
+            acc2[j] = first ? kj : fast::pk_fma(fast::bc(wgt), kj, acc2[j]);
+            if (j >= 1) {                                           // words 0..2 feed nothing back (word 2 rides along in its pair)
+                const f32x2 xj = fast::pk_fma(fast::bc(h), kj, x02[j]);
+                xt[PA[j]] = xj.x; xt[PB[j]] = xj.y;
+            }
+        }
+    };
     dynamics_fast<STRAIGHT>(P, C, f.x0, f.t0, f.d0, k);                            // k1
-#pragma unroll
-    for (int i = 0; i < 12; ++i) acc[i] = k[i];
-#pragma unroll
-    for (int i = 3; i < 12; ++i) xt[i] = __builtin_fmaf(hdt, k[i], f.x0[i]);
-    T dm = trig_rotate(f.t0, hdt * k[6], hdt * k[7], hdt * k[8], tt);
+    stage(hdt, T(1), true);
+    T dm = trig_rotate_scaled(f.t0, hdt, k[6], k[7], k[8], tt);
     dynamics_fast<STRAIGHT>(P, C, xt, tt, dm, k);                        // k2
-#pragma unroll
-    for (int i = 0; i < 12; ++i) acc[i] = __builtin_fmaf(T(2), k[i], acc[i]);
-#pragma unroll
-    for (int i = 3; i < 12; ++i) xt[i] = __builtin_fmaf(hdt, k[i], f.x0[i]);
-    dm = trig_rotate(f.t0, hdt * k[6], hdt * k[7], hdt * k[8], tt);
+    stage(hdt, T(2), false);
+    dm = trig_rotate_scaled(f.t0, hdt, k[6], k[7], k[8], tt);
     dynamics_fast<STRAIGHT>(P, C, xt, tt, dm, k);                        // k3
-#pragma unroll
-    for (int i = 0; i < 12; ++i) acc[i] = __builtin_fmaf(T(2), k[i], acc[i]);
-#pragma unroll
-    for (int i = 3; i < 12; ++i) xt[i] = __builtin_fmaf(fdt, k[i], f.x0[i]);
-    dm = trig_rotate(f.t0, fdt * k[6], fdt * k[7], fdt * k[8], tt);
+    stage(fdt, T(2), false);
+    dm = trig_rotate_scaled(f.t0, fdt, k[6], k[7], k[8], tt);
     dynamics_fast<STRAIGHT>(P, C, xt, tt, dm, k);                        // k4
-    T inc[FD_NX];
+    T ksum[FD_NX], inc[FD_NX];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const f32x2 ks = acc2[j] + (f32x2){ k[PA[j]], k[PB[j]] };
+        const f32x2 in2 = fast::bc(dt6) * ks;
+        ksum[PA[j]] = ks.x; ksum[PB[j]] = ks.y;
+        inc[PA[j]] = in2.x; inc[PB[j]] = in2.y;
+    }
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
-        const T ksum = acc[i] + k[i];
-        inc[i] = dt6 * ksum;
         // fp32 storage: the accumulate is spelled as the one fused instruction, so that no build's contraction heuristics decide
-        if constexpr (sizeof(S) == 4) x[i] = __builtin_fmaf(dt6, ksum, x[i]);
+        if constexpr (sizeof(S) == 4) x[i] = __builtin_fmaf(dt6, ksum[i], x[i]);
         else x[i] += S(inc[i]);
         // the body-rate clamp (:273) sits in the straight-line path, as a select in the storage type: it is the STICKY clamp -- an
         // aircraft tumbling against it trips it on every sub-step, and behind the wave-level branch below it cost the wave
@@ -727,9 +823,10 @@ FD_DEV void rk4_fast_step(const Params<float>& P, const Limits<S>& Lm, const Con
     }
     f.d0 = trig_rotate(f.t0, inc[6], inc[7], inc[8], f.t0);
     // one predicate for every clamp / wrap / guard of :256-291, evaluated on the fp32 copy
-    T sum = f.x0[0];
+    f32x2 sum2 = { f.x0[0], f.x0[1] };                   // all finite <=> the sum is finite: only its finiteness is read
 #pragma unroll
-    for (int i = 1; i < 12; ++i) sum += f.x0[i];
+    for (int j = 1; j < 6; ++j) sum2 += (f32x2){ f.x0[2 * j], f.x0[2 * j + 1] };
+    const T sum = sum2.x + sum2.y;
     const T vmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(f.x0[3]), __builtin_fabsf(f.x0[4])), __builtin_fabsf(f.x0[5]));
     const T amax = __builtin_fmaxf(__builtin_fabsf(f.x0[6]), __builtin_fabsf(f.x0[8]));
     // Two classes.  `lim`: the velocity clamp, ground contact and the roll / yaw re-wraps (:262, :266, :270, :276-283) leave
@@ -844,10 +941,10 @@ FD_DEV Derived<float> derived_fast(FastRK& f)
     const Trig& t = f.t0;
     d.airspeed = fast::sqrt(__builtin_fmaf(u, u, __builtin_fmaf(v, v, w * w)));
     d.altitude = -f.x0[2];
-    const float sv_cw = __builtin_fmaf(t.sphi, v, t.cphi * w);
-    const float ah = __builtin_fmaf(t.cth, u, t.sth * sv_cw);
-    const float bh = __builtin_fmaf(t.cphi, v, -(t.sphi * w));
-    const float vn = __builtin_fmaf(t.cpsi, ah, -(t.spsi * bh)), ve = __builtin_fmaf(t.spsi, ah, t.cpsi * bh);
+    const float sv_cw = __builtin_fmaf(t.phi.x, v, t.phi.y * w);
+    const float ah = __builtin_fmaf(t.th.y, u, t.th.x * sv_cw);
+    const float bh = __builtin_fmaf(t.phi.y, v, -(t.phi.x * w));
+    const float vn = __builtin_fmaf(t.psi.y, ah, -(t.psi.x * bh)), ve = __builtin_fmaf(t.psi.x, ah, t.psi.y * bh);
     d.heading = fast::atan2(ve, vn);
     d.ground_speed = fast::sqrt(__builtin_fmaf(vn, vn, ve * ve));
     return d;
