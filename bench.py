@@ -311,10 +311,10 @@ def timed_region(wl, args, world, min_region_s=0.05, max_repeats=31):
         loop.run(K)
         ev1.record(stream)
         torch.cuda.synchronize()
+        wall = time.perf_counter() - t0                # this rank's K steps; the MAX over ranks below is the job's time
         if grp:
-            torch.distributed.barrier()
-        wall = time.perf_counter() - t0
-        dev_ms = ev0.elapsed_time(ev1)
+            torch.distributed.barrier()                # closing bracket: nobody leaves (or starts the next repeat) early --
+        dev_ms = ev0.elapsed_time(ev1)                 # its own latency (an all-reduce + sync) is not part of the K steps
         if grp:
             t = torch.tensor([wall], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
