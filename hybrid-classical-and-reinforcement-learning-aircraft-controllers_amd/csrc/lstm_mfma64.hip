@@ -274,14 +274,7 @@ lstm_cell_mfma64_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const u
     // (Tried: the 8 x 32 output tiles transposed through a per-wave LDS buffer and stored as ONE dwordx4 / dwordx2 instruction per
     // group instead of 4 + 4 word stores -- 16 instead of 64 store instructions per slice, the same lines: 70.5 us against 70.3.
     // What the stores cost is their lines, not their number.)
-    // the plain arithmetic of a stage runs on element PAIRS (v_pk_fma / v_pk_mul / v_pk_add: with one wave per SIMD an
-    // instruction costs an issue slot of ~5 cycles whatever it does, so two elements per instruction halve that share of the
-    // epilogue; the same products and FMAs, bit-identical results); transcendentals, loads and stores stay per element
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    auto pkfma = [](f32x2_t x, f32x2_t y, f32x2_t z) { return __builtin_elementwise_fma(x, y, z); };
-    auto bc2 = [](float v) { return (f32x2_t){v, v}; };
-    auto acc2 = [](const f32x16_t& v, int e) { return (f32x2_t){v[e], v[e + 1]}; };
-    struct FO { f32x2_t kp[2], cp[2], a[2], b[2], c[2], t[2]; };
+    struct FO { float kp[4], cp[4], a[4], b[4], c[4], t[4]; };
     auto fo_stage = [&](FO& s, auto waitcp_c, auto SG, auto M) {
         constexpr int sg = decltype(SG)::value, m = decltype(M)::value;
         constexpr bool WAITCP = decltype(waitcp_c)::value;
@@ -298,70 +291,70 @@ lstm_cell_mfma64_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const u
                 if constexpr (WAITCP) wait_vm<4 * (7 - sg) + p1_dma_after + p0_dma_before + p0_stores_before_sg(sg)>();
             }
             const float4 k4 = *reinterpret_cast<const float4*>(&s_keep[uwave * 64 + 32 * t + 8 * j + 4 * hf]);
-            s.kp[0] = (f32x2_t){k4.x, k4.y}; s.kp[1] = (f32x2_t){k4.z, k4.w};
-            sfor<0, 2>([&](auto P) { constexpr int p = decltype(P)::value; s.cp[p] = (f32x2_t){rd_a<AG_CP + 16 * t + 4 * j + 2 * p>(), rd_a<AG_CP + 16 * t + 4 * j + 2 * p + 1>()}; });
-            sfor<0, 2>([&](auto P) { constexpr int p = decltype(P)::value; s.a[p] = pkfma(acc2(aB[0][t], 4 * j + 2 * p), bc2(-L2E), bc2(pbf)); });
+            s.kp[0] = k4.x; s.kp[1] = k4.y; s.kp[2] = k4.z; s.kp[3] = k4.w;
+            sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.cp[i] = rd_a<AG_CP + 16 * t + 4 * j + i>(); });
+            sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.a[i] = __builtin_fmaf(aB[0][t][4 * j + i], -L2E, pbf); });
         } else if constexpr (m == 1) {
-            sfor<0, 2>([&](auto P) { constexpr int p = decltype(P)::value; s.a[p] = (f32x2_t){ex2(s.a[p].x), ex2(s.a[p].y)}; });
+            sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.a[i] = ex2(s.a[i]); });
         } else if constexpr (m == 2) {
-            sfor<0, 2>([&](auto P) { constexpr int p = decltype(P)::value; s.a[p] = bc2(1.0f) + s.a[p]; });
-            sfor<0, 2>([&](auto P) { constexpr int p = decltype(P)::value; s.b[p] = pkfma(acc2(aB[1][t], 4 * j + 2 * p), bc2(-L2E), bc2(pbo)); });
+            sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.a[i] = 1.0f + s.a[i]; });
+            sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.b[i] = __builtin_fmaf(aB[1][t][4 * j + i], -L2E, pbo); });
         } else if constexpr (m == 3) {
-            sfor<0, 2>([&](auto P) { constexpr int p = decltype(P)::value; s.a[p] = (f32x2_t){rcp(s.a[p].x), rcp(s.a[p].y)}; });          // sigmoid(f)
+            sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.a[i] = rcp(s.a[i]); });          // sigmoid(f)
         } else if constexpr (m == 4) {
-            sfor<0, 2>([&](auto P) { constexpr int p = decltype(P)::value; s.cp[p] = s.cp[p] * s.kp[p]; });
-            sfor<0, 2>([&](auto P) { constexpr int p = decltype(P)::value; s.c[p] = pkfma(s.a[p], s.cp[p], (f32x2_t){ig[t][4 * j + 2 * p], ig[t][4 * j + 2 * p + 1]}); });
-            sfor<0, 2>([&](auto P) { constexpr int p = decltype(P)::value; s.t[p] = s.c[p] * bc2(2.0f * L2E); });
+            sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.cp[i] *= s.kp[i]; });
+            sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.c[i] = __builtin_fmaf(s.a[i], s.cp[i], ig[t][4 * j + i]); });
+            sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.t[i] = s.c[i] * (2.0f * L2E); });
         } else if constexpr (m == 5) {
-            sfor<0, 2>([&](auto P) { constexpr int p = decltype(P)::value; s.t[p] = (f32x2_t){ex2(s.t[p].x), ex2(s.t[p].y)}; });
+            sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.t[i] = ex2(s.t[i]); });
             sfor<0, 4>([&](auto I) {
                 constexpr int i = decltype(I)::value;
 #if defined(FD64_ABL_NOSTORE)
-                { const float cv_ = s.c[i >> 1][i & 1]; asm volatile("" :: "v"(cv_)); }
+                { const float cv_ = s.c[i]; asm volatile("" :: "v"(cv_)); }
 #else
-                *reinterpret_cast<float*>(reinterpret_cast<char*>(cb) + (lo * 4u + uint32_t(i * H * 4))) = s.c[i >> 1][i & 1];
+                *reinterpret_cast<float*>(reinterpret_cast<char*>(cb) + (lo * 4u + uint32_t(i * H * 4))) = s.c[i];
 #endif
             });
         } else if constexpr (m == 6) {
-            sfor<0, 2>([&](auto P) { constexpr int p = decltype(P)::value; s.t[p] = s.t[p] + bc2(1.0f); });
-            sfor<0, 2>([&](auto P) { constexpr int p = decltype(P)::value; s.b[p] = (f32x2_t){ex2(s.b[p].x), ex2(s.b[p].y)}; });
+            sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.t[i] = s.t[i] + 1.0f; });
+            sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.b[i] = ex2(s.b[i]); });
         } else if constexpr (m == 7) {
-            sfor<0, 2>([&](auto P) { constexpr int p = decltype(P)::value; s.t[p] = (f32x2_t){rcp(s.t[p].x), rcp(s.t[p].y)}; });
-            sfor<0, 2>([&](auto P) { constexpr int p = decltype(P)::value; s.b[p] = bc2(1.0f) + s.b[p]; });
+            sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.t[i] = rcp(s.t[i]); });
+            sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.b[i] = 1.0f + s.b[i]; });
         } else if constexpr (m == 8) {
-            sfor<0, 2>([&](auto P) { constexpr int p = decltype(P)::value; s.b[p] = (f32x2_t){rcp(s.b[p].x), rcp(s.b[p].y)}; });          // sigmoid(o)
-            sfor<0, 2>([&](auto P) { constexpr int p = decltype(P)::value; s.t[p] = pkfma(bc2(-2.0f), s.t[p], bc2(1.0f)); });   // tanh(c')
+            sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.b[i] = rcp(s.b[i]); });          // sigmoid(o)
+            sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.t[i] = __builtin_fmaf(-2.0f, s.t[i], 1.0f); });   // tanh(c')
         } else if constexpr (m == 9) {
-            sfor<0, 2>([&](auto P) { constexpr int p = decltype(P)::value; s.t[p] = s.t[p] * s.b[p]; });
+            sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.t[i] = s.t[i] * s.b[i]; });
         } else if constexpr (m == 10) {
             sfor<0, 4>([&](auto I) {
                 constexpr int i = decltype(I)::value;
 #if defined(FD64_ABL_NOSTORE)
-                { const float hv_ = s.t[i >> 1][i & 1]; asm volatile("" :: "v"(hv_)); }
+                { const float hv_ = s.t[i]; asm volatile("" :: "v"(hv_)); }
 #else
-                *reinterpret_cast<__bf16*>(reinterpret_cast<char*>(hb) + (lo * 2u + uint32_t(i * H * 2))) = static_cast<__bf16>(s.t[i >> 1][i & 1]);
+                *reinterpret_cast<__bf16*>(reinterpret_cast<char*>(hb) + (lo * 2u + uint32_t(i * H * 2))) = static_cast<__bf16>(s.t[i]);
 #endif
             });
         }
     };
     // ---- the (i, g) epilogue of the current slice: ig = sigmoid(i) tanh(g), in element pairs A = (0, 1), B = (2, 3) of the
     // group so that no gap carries more than one transcendental pair; the slice's c_prev loads ride along (a[AG_CP ..])
-    struct IG { f32x2_t xi[2], xg[2]; };
+    struct IG { float xi[4], xg[4]; };
     auto ig_stage = [&](IG& s, float bi, float bg, uint32_t col, auto SG, auto M) {
         constexpr int sg = decltype(SG)::value, m = decltype(M)::value;
         constexpr int t = sg >> 2, j = sg & 3;
-        auto pairop = [&](auto P, auto&& f) { f(P); };                     // one packed operation on element pair P
+        auto pairop = [&](auto P, auto&& f) { constexpr int p = decltype(P)::value; f(std::integral_constant<int, 2 * p>{}); f(std::integral_constant<int, 2 * p + 1>{}); };
         using A_ = std::integral_constant<int, 0>; using B_ = std::integral_constant<int, 1>;
-        auto xi_ = [&](auto P) { constexpr int p = decltype(P)::value; s.xi[p] = pkfma(acc2(aA[0][t], 4 * j + 2 * p), bc2(-L2E), bc2(bi)); };
-        auto xg_ = [&](auto P) { constexpr int p = decltype(P)::value; s.xg[p] = pkfma(acc2(aA[1][t], 4 * j + 2 * p), bc2(2.0f * L2E), bc2(bg)); };
-        auto ei_ = [&](auto P) { constexpr int p = decltype(P)::value; s.xi[p] = (f32x2_t){ex2(s.xi[p].x), ex2(s.xi[p].y)}; };
-        auto eg_ = [&](auto P) { constexpr int p = decltype(P)::value; s.xg[p] = (f32x2_t){ex2(s.xg[p].x), ex2(s.xg[p].y)}; };
-        auto ai_ = [&](auto P) { constexpr int p = decltype(P)::value; s.xi[p] = bc2(1.0f) + s.xi[p]; };
-        auto ag_ = [&](auto P) { constexpr int p = decltype(P)::value; s.xg[p] = s.xg[p] + bc2(1.0f); };
-        auto si_ = [&](auto P) { constexpr int p = decltype(P)::value; s.xi[p] = (f32x2_t){rcp(s.xi[p].x), rcp(s.xi[p].y)}; };
-        auto rg_ = [&](auto P) { constexpr int p = decltype(P)::value; s.xg[p] = (f32x2_t){rcp(s.xg[p].x), rcp(s.xg[p].y)}; };
-        auto tg_ = [&](auto P) { constexpr int p = decltype(P)::value; s.xg[p] = pkfma(bc2(-2.0f), s.xg[p], bc2(1.0f)); };
-        auto ig_ = [&](auto P) { constexpr int p = decltype(P)::value; const f32x2_t v = s.xi[p] * s.xg[p]; ig[t][4 * j + 2 * p] = v.x; ig[t][4 * j + 2 * p + 1] = v.y; };
+        auto xi_ = [&](auto I) { constexpr int i = decltype(I)::value; s.xi[i] = __builtin_fmaf(aA[0][t][4 * j + i], -L2E, bi); };
+        auto xg_ = [&](auto I) { constexpr int i = decltype(I)::value; s.xg[i] = __builtin_fmaf(aA[1][t][4 * j + i], 2.0f * L2E, bg); };
+        auto ei_ = [&](auto I) { constexpr int i = decltype(I)::value; s.xi[i] = ex2(s.xi[i]); };
+        auto eg_ = [&](auto I) { constexpr int i = decltype(I)::value; s.xg[i] = ex2(s.xg[i]); };
+        auto ai_ = [&](auto I) { constexpr int i = decltype(I)::value; s.xi[i] = 1.0f + s.xi[i]; };
+        auto ag_ = [&](auto I) { constexpr int i = decltype(I)::value; s.xg[i] = s.xg[i] + 1.0f; };
+        auto si_ = [&](auto I) { constexpr int i = decltype(I)::value; s.xi[i] = rcp(s.xi[i]); };
+        auto rg_ = [&](auto I) { constexpr int i = decltype(I)::value; s.xg[i] = rcp(s.xg[i]); };
+        auto tg_ = [&](auto I) { constexpr int i = decltype(I)::value; s.xg[i] = __builtin_fmaf(-2.0f, s.xg[i], 1.0f); };
+        auto ig_ = [&](auto I) { constexpr int i = decltype(I)::value; ig[t][4 * j + i] = s.xi[i] * s.xg[i]; };
         const float* cpb = c_prev + (urow0 + 32 * t + 8 * j) * H;         // wave-uniform
         const uint32_t lo = (uoff + col) * 4u;
         if constexpr (m == 0) { pairop(A_{}, xi_); ld_a1_s<AG_CP + 16 * t + 4 * j + 0, 0>(cpb, lo); }

@@ -34,7 +34,6 @@ namespace {
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int H = 256, EMB = 128, FEAT = 128, OBS = 18;
@@ -220,13 +219,7 @@ policy_fe64_kernel(const float* __restrict__ obs /*[B][18]*/, const uint8_t* __r
     // micro-stage order: groups in pairs, the two groups of a pair alternate (dependent operations sit eight instructions apart)
     constexpr int NS = 11;                              // micro-stages per group in both epilogues
     constexpr int NMICRO = 8 * NS;
-    // a micro-stage is one operation on four elements; the plain arithmetic ones are TWO v_pk_* instructions (with one wave per
-    // SIMD an instruction costs an issue slot of ~5 cycles whatever it does: packed halves the count, same values), the
-    // transcendental and clamp ones four scalar instructions
-    struct GS { f32x4_t b0, b1; f32x2_t x[2], y[2], z[2]; };
-    auto pair_of = [](const f32x16_t& a, int e) { return (f32x2_t){a[e], a[e + 1]}; };
-    auto pkfma = [](f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); };
-    auto bc2 = [](float v) { return (f32x2_t){v, v}; };
+    struct GS { f32x4_t b0, b1; float x[4], y[4], z[4]; };
 
     auto layer = [&](auto ks_c, auto in_c, auto out_c, int sb, int off0, int next_off, int next_np) {
         constexpr int KS = decltype(ks_c)::value, IN = decltype(in_c)::value, OUT = decltype(out_c)::value;
@@ -241,16 +234,16 @@ policy_fe64_kernel(const float* __restrict__ obs /*[B][18]*/, const uint8_t* __r
             if constexpr (st == 0) {
                 s.b0 = *reinterpret_cast<const f32x4_t*>(&s_b[sb + 32 * sl + 8 * q + 4 * hf]);
                 s.b1 = *reinterpret_cast<const f32x4_t*>(&s_b[sb + 2 * H + 32 * sl + 8 * q + 4 * hf]);
-            } else if constexpr (st == 1) { sfor<0, 2>([&](auto J) { constexpr int j = decltype(J)::value; s.x[j] = pkfma(pair_of(aA[0][t], 4 * q + 2 * j), bc2(-L2E), j ? s.b0.zw : s.b0.xy); });
-            } else if constexpr (st == 2) { sfor<0, 2>([&](auto J) { constexpr int j = decltype(J)::value; s.x[j] = (f32x2_t){ex2(s.x[j].x), ex2(s.x[j].y)}; });
-            } else if constexpr (st == 3) { sfor<0, 2>([&](auto J) { constexpr int j = decltype(J)::value; s.y[j] = pkfma(pair_of(aA[1][t], 4 * q + 2 * j), bc2(-2.0f * L2E), j ? s.b1.zw : s.b1.xy); });
-            } else if constexpr (st == 4) { sfor<0, 2>([&](auto J) { constexpr int j = decltype(J)::value; s.y[j] = (f32x2_t){__builtin_amdgcn_fmed3f(s.y[j].x, -40.0f, 40.0f), __builtin_amdgcn_fmed3f(s.y[j].y, -40.0f, 40.0f)}; });
-            } else if constexpr (st == 5) { sfor<0, 2>([&](auto J) { constexpr int j = decltype(J)::value; s.y[j] = (f32x2_t){ex2(s.y[j].x), ex2(s.y[j].y)}; });
-            } else if constexpr (st == 6) { sfor<0, 2>([&](auto J) { constexpr int j = decltype(J)::value; s.z[j] = bc2(1.0f) + s.y[j]; });
-            } else if constexpr (st == 7) { sfor<0, 2>([&](auto J) { constexpr int j = decltype(J)::value; s.z[j] = pkfma(s.z[j], s.x[j], s.z[j]); });
-            } else if constexpr (st == 8) { sfor<0, 2>([&](auto J) { constexpr int j = decltype(J)::value; s.z[j] = (f32x2_t){rcp(s.z[j].x), rcp(s.z[j].y)}; });
-            } else if constexpr (st == 9) { sfor<0, 2>([&](auto J) { constexpr int j = decltype(J)::value; s.y[j] = bc2(1.0f) - s.y[j]; });
-            } else { sfor<0, 2>([&](auto J) { constexpr int j = decltype(J)::value; const f32x2_t v = s.y[j] * s.z[j]; ig[t][4 * q + 2 * j] = v.x; ig[t][4 * q + 2 * j + 1] = v.y; }); }
+            } else if constexpr (st == 1) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.x[i] = __builtin_fmaf(aA[0][t][4 * q + i], -L2E, s.b0[i]); });
+            } else if constexpr (st == 2) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.x[i] = ex2(s.x[i]); });
+            } else if constexpr (st == 3) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.y[i] = __builtin_fmaf(aA[1][t][4 * q + i], -2.0f * L2E, s.b1[i]); });
+            } else if constexpr (st == 4) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.y[i] = __builtin_amdgcn_fmed3f(s.y[i], -40.0f, 40.0f); });
+            } else if constexpr (st == 5) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.y[i] = ex2(s.y[i]); });
+            } else if constexpr (st == 6) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.z[i] = 1.0f + s.y[i]; });
+            } else if constexpr (st == 7) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.z[i] = __builtin_fmaf(s.z[i], s.x[i], s.z[i]); });
+            } else if constexpr (st == 8) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.z[i] = rcp(s.z[i]); });
+            } else if constexpr (st == 9) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.y[i] = 1.0f - s.y[i]; });
+            } else { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; ig[t][4 * q + i] = s.y[i] * s.z[i]; }); }
         };
         // o epilogue of the pending slice: h = sigmoid(o) tanh(c), c = ig in (-1, 1): h = (1 - E) / ((1 + E)(1 + O)), E = 2^(-2 c log2 e)
         auto h_micro = [&](auto UU) {
@@ -258,16 +251,16 @@ policy_fe64_kernel(const float* __restrict__ obs /*[B][18]*/, const uint8_t* __r
             constexpr int t = gq >> 2, q = gq & 3;
             GS& s = gs[gq];
             if constexpr (st == 0) { s.b0 = *reinterpret_cast<const f32x4_t*>(&s_b[sb + 3 * H + 32 * psl + 8 * q + 4 * hf]);
-            } else if constexpr (st == 1) { sfor<0, 2>([&](auto J) { constexpr int j = decltype(J)::value; s.x[j] = pkfma(pair_of(aB[t], 4 * q + 2 * j), bc2(-L2E), j ? s.b0.zw : s.b0.xy); });
-            } else if constexpr (st == 2) { sfor<0, 2>([&](auto J) { constexpr int j = decltype(J)::value; s.x[j] = (f32x2_t){ex2(s.x[j].x), ex2(s.x[j].y)}; });
-            } else if constexpr (st == 3) { sfor<0, 2>([&](auto J) { constexpr int j = decltype(J)::value; s.y[j] = (f32x2_t){ig[t][4 * q + 2 * j], ig[t][4 * q + 2 * j + 1]} * bc2(-2.0f * L2E); });
-            } else if constexpr (st == 4) { sfor<0, 2>([&](auto J) { constexpr int j = decltype(J)::value; s.y[j] = (f32x2_t){ex2(s.y[j].x), ex2(s.y[j].y)}; });
-            } else if constexpr (st == 5) { sfor<0, 2>([&](auto J) { constexpr int j = decltype(J)::value; s.z[j] = bc2(1.0f) + s.y[j]; });
-            } else if constexpr (st == 6) { sfor<0, 2>([&](auto J) { constexpr int j = decltype(J)::value; s.z[j] = pkfma(s.z[j], s.x[j], s.z[j]); });
-            } else if constexpr (st == 7) { sfor<0, 2>([&](auto J) { constexpr int j = decltype(J)::value; s.z[j] = (f32x2_t){rcp(s.z[j].x), rcp(s.z[j].y)}; });
-            } else if constexpr (st == 8) { sfor<0, 2>([&](auto J) { constexpr int j = decltype(J)::value; s.y[j] = bc2(1.0f) - s.y[j]; });
-            } else if constexpr (st == 9) { sfor<0, 2>([&](auto J) { constexpr int j = decltype(J)::value; s.z[j] = s.y[j] * s.z[j]; });
-            } else { hp[t][2 * q] = pack2(s.z[0].x, s.z[0].y); hp[t][2 * q + 1] = pack2(s.z[1].x, s.z[1].y); }
+            } else if constexpr (st == 1) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.x[i] = __builtin_fmaf(aB[t][4 * q + i], -L2E, s.b0[i]); });
+            } else if constexpr (st == 2) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.x[i] = ex2(s.x[i]); });
+            } else if constexpr (st == 3) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.y[i] = ig[t][4 * q + i] * (-2.0f * L2E); });
+            } else if constexpr (st == 4) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.y[i] = ex2(s.y[i]); });
+            } else if constexpr (st == 5) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.z[i] = 1.0f + s.y[i]; });
+            } else if constexpr (st == 6) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.z[i] = __builtin_fmaf(s.z[i], s.x[i], s.z[i]); });
+            } else if constexpr (st == 7) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.z[i] = rcp(s.z[i]); });
+            } else if constexpr (st == 8) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.y[i] = 1.0f - s.y[i]; });
+            } else if constexpr (st == 9) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.z[i] = s.y[i] * s.z[i]; });
+            } else { hp[t][2 * q] = pack2(s.z[0], s.z[1]); hp[t][2 * q + 1] = pack2(s.z[2], s.z[3]); }
         };
         // the pending slice's packed h -> output slab (the register index must be an immediate: one arm per slice)
         auto commit = [&]() {
