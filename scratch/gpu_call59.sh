@@ -1,0 +1,8 @@
+# HEAD check (packed env arithmetic, original gate epilogues): whole GPU suite, smoke, default bench; cfg-4 training + evaluation
+R=$GRAFT_REPO_ROOT
+cd $R
+timeout -k 10 700 python -m pytest tests -m gpu -x -q > gpurun_out/c59_gpu_tests.log 2>&1; echo suite rc=$?
+timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/c59_smoke.log 2>&1; echo smoke rc=$?
+timeout -k 10 300 python bench.py > gpurun_out/c59_bench.json 2> gpurun_out/c59_bench.err; echo bench rc=$?
+bash scratch/run_cfg4.sh > gpurun_out/c59_cfg4.log 2>&1; echo cfg4 rc=$?
+tail -2 gpurun_out/c59_gpu_tests.log; tail -1 gpurun_out/c59_smoke.log; cut -c1-260 gpurun_out/c59_bench.json; echo; tail -25 gpurun_out/c59_cfg4.log
