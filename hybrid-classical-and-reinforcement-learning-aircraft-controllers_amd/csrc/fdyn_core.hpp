@@ -83,7 +83,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 FD_DEV f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 FD_DEV f32x2 bc(float x) { return (f32x2){ x, x }; }
 // (x, undefined): an operand of which the packed instruction reads the LOW half for both results -- no copy to build (x, x)
-FD_DEV f32x2 lo_only(float x) { f32x2 r; r.x = x; return r; }      // r.y deliberately unset: (x, x) would cost a v_mov
+// r.y deliberately unset -- the packed instruction never reads it (op_sel_hi 0 for that operand).  (x, x) costs a v_mov per use,
+// and so does a frozen unspecified value (__builtin_nondeterministic_value: +8 instructions per sub-step).
+FD_DEV f32x2 lo_only(float x) { f32x2 r; r.x = x; return r; }
 // A plane rotation negates ONE half of a pair.  The hardware has the per-half modifier (neg_lo / neg_hi); LLVM does not select
 // it for packed fp32 (it emits v_pk_add_f32 x, 0 neg + v_mov: two instructions per negated half), so the two forms a rotation
 // needs are spelled as ONE instruction each.  Their operands come from plain VALU instructions only (FMAs and products), never
