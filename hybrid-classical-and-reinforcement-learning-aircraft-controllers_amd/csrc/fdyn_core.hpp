@@ -346,16 +346,25 @@ template <typename T> struct Params {
     //                computed with the fp32 sincos (25 instructions; the fp64 ocml pair is ~1500 cycles on the path every
     //                wave of the workgroup waits for) and skipped in the fp64 kernels
     static constexpr int FD_ND_LANES = 7;
+    // word of the block a derive lane starts from (so that a caller can issue that load EARLY, ahead of its per-aircraft loads)
+    static FD_DEV int derive_source(int lane)
+    {
+        return lane == 0 ? FD_P_MASS : (lane == 1 ? FD_P_IXX : (lane == 2 ? FD_P_IYY : (lane == 3 ? FD_P_IZZ : (lane == 4 ? FD_P_THRUST_ZERO_VELOCITY
+               : (lane == 5 ? FD_P_MAX_ALPHA_RAD : FD_P_MAX_PITCH_RAD)))));
+    }
     template <bool FAST>
     static FD_DEV void derive_lane(int lane, const double* __restrict__ src, double* blk)
     {
+        derive_lane_from<FAST>(lane, src[derive_source(lane < FD_ND_LANES ? lane : 0)], blk);
+    }
+    template <bool FAST>
+    static FD_DEV void derive_lane_from(int lane, double a, double* blk)                 // a = block[derive_source(lane)]
+    {
         if (lane < 5) {
-            const int from = lane == 0 ? FD_P_MASS : (lane == 1 ? FD_P_IXX : (lane == 2 ? FD_P_IYY : (lane == 3 ? FD_P_IZZ : FD_P_THRUST_ZERO_VELOCITY)));
             const int to = lane == 0 ? FD_PD_INV_MASS : (lane == 1 ? FD_PD_INV_IXX : (lane == 2 ? FD_PD_INV_IYY : (lane == 3 ? FD_PD_INV_IZZ : FD_PD_INV_THRUST_ZERO_V)));
-            blk[to] = 1.0 / src[from];
+            blk[to] = 1.0 / a;
         } else if (FAST && lane < FD_ND_LANES) {
             const bool is_alpha = lane == 5;
-            const double a = src[is_alpha ? FD_P_MAX_ALPHA_RAD : FD_P_MAX_PITCH_RAD];
             float snf, csf;
             fast::sincos(float(a), snf, csf);
             const double sn = snf, cs = csf;

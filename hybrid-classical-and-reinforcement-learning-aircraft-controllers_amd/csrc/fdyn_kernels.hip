@@ -50,6 +50,36 @@ __device__ __forceinline__ void stage_params(double* s_params, const double* __r
     }
 }
 
+// The same in two halves, for a kernel whose launch is one burst of per-aircraft loads (the env step at one wave per SIMD): loads
+// return IN ORDER, so a parameter word requested after the state is not in LDS -- and the barrier not passed -- before the whole
+// burst has landed.  `early` issues the block's loads FIRST; `finish` stores them once they are back, ahead of the state.
+struct StagedParamWords { double v0, v1, d; };
+__device__ __forceinline__ StagedParamWords stage_params_early(const double* __restrict__ params, int n_types)
+{
+    StagedParamWords w;                                           // FD_MAX_TYPES * FD_NP_USED <= 2 * FD_BLOCK: two words per thread
+    const int i0 = threadIdx.x, i1 = FD_BLOCK + threadIdx.x;
+    const int t0 = i0 / FD_NP_USED, t1 = i1 / FD_NP_USED;
+    w.v0 = i0 < n_types * FD_NP_USED ? params[t0 * FD_NP + (i0 - t0 * FD_NP_USED)] : 0.0;
+    w.v1 = i1 < n_types * FD_NP_USED ? params[t1 * FD_NP + (i1 - t1 * FD_NP_USED)] : 0.0;
+    constexpr int NDL = Params<double>::FD_ND_LANES;
+    const int t = threadIdx.x / NDL;
+    w.d = int(threadIdx.x) < n_types * NDL ? params[t * FD_NP + Params<double>::derive_source(threadIdx.x - t * NDL)] : 1.0;
+    return w;
+}
+template <bool FAST>
+__device__ __forceinline__ void stage_params_finish(double* s_params, const StagedParamWords& w, int n_types)
+{
+    const int i0 = threadIdx.x, i1 = FD_BLOCK + threadIdx.x;
+    const int t0 = i0 / FD_NP_USED, t1 = i1 / FD_NP_USED;
+    if (i0 < n_types * FD_NP_USED) s_params[t0 * FD_NP_STAGED + (i0 - t0 * FD_NP_USED)] = w.v0;
+    if (i1 < n_types * FD_NP_USED) s_params[t1 * FD_NP_STAGED + (i1 - t1 * FD_NP_USED)] = w.v1;
+    constexpr int NDL = Params<double>::FD_ND_LANES;
+    if (int(threadIdx.x) < n_types * NDL) {
+        const int t = threadIdx.x / NDL;
+        Params<double>::derive_lane_from<FAST>(threadIdx.x - t * NDL, w.d, s_params + t * FD_NP_STAGED);
+    }
+}
+
 // Cascade constants -> LDS in the glue type, plus the two derived reciprocals the fp32 guidance uses
 template <typename G>
 __device__ __forceinline__ void stage_cascade_consts(G* s_consts, const double* __restrict__ consts)
@@ -676,19 +706,26 @@ rate_env_step_kernel(S* __restrict__ xs, typename EnvOf<S, T>::type* __restrict_
     // (80 quarter-rate 64-bit multiplies, ~2.5 k cycles) were paid by three waves in four, the slowest ones included.  The
     // episode counter is therefore loaded FIRST (loads return in order).  The register-capped build keeps the lazy draw: its
     // neighbour wave hides it, and 24 more live registers would spill.
+    // Order of the requests = order of arrival: the parameter words (the barrier below waits for them), the episode counter (the
+    // reset record), what the FIRST dynamics evaluation reads (velocities, angles, rates, the action), and only then the position
+    // (first touched by the accumulate at the end of sub-step 1) and the env words (touched after the 20 sub-steps) -- the second
+    // half of the burst lands under the first sub-step instead of in front of it.
     S rec_pre[FD_NR];
     const bool pre_drawn = !OCC2 && pool == nullptr && auto_reset != 0;
+    const StagedParamWords spw = stage_params_early(params, n_types);
     if (active) {
-        step = eis[FD_EI_STEP * n + i];
         episode = eis[FD_EI_EPISODE * n + i];
 #pragma unroll
-        for (int k = 0; k < FD_NX; ++k) x[k] = xs[k * n + i];
-        env_load<E>(e, es, n, i, uses_sched);
+        for (int k = 3; k < FD_NX; ++k) x[k] = xs[k * n + i];
         if (actions) av = reinterpret_cast<const float4*>(actions)[i];
         ty = lane_type(type, i, n_types);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) x[k] = xs[k * n + i];
+        step = eis[FD_EI_STEP * n + i];
+        env_load<E>(e, es, n, i, uses_sched);
         if (pre_drawn) device_reset_record<S>(seed, uint32_t(i), uint32_t(episode), ec, rec_pre);
     }
-    stage_params<sizeof(T) == 4>(s_params, params, n_types);
+    stage_params_finish<sizeof(T) == 4>(s_params, spw, n_types);
     if (pid_mode) {
         stage(s_pid_cfg, pid_cfg, 3 * FD_NPC);
         for (int k = threadIdx.x; k < FD_NC; k += blockDim.x) s_consts[k] = S(casc_consts[k]);
