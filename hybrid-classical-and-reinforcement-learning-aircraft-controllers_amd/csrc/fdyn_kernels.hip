@@ -712,7 +712,11 @@ rate_env_step_kernel(S* __restrict__ xs, typename EnvOf<S, T>::type* __restrict_
     // half of the burst lands under the first sub-step instead of in front of it.
     S rec_pre[FD_NR];
     const bool pre_drawn = !OCC2 && pool == nullptr && auto_reset != 0;
-    const StagedParamWords spw = stage_params_early(params, n_types);
+    // (fp32-evaluation builds only: in the fp64 build the split left a dead 20-byte private segment in the kernel descriptor --
+    // never accessed, but a scratch set-up per launch -- and that build is the parity reference, not the benched one)
+    constexpr bool EARLY_PARAMS = sizeof(T) == 4;
+    StagedParamWords spw = { 0.0, 0.0, 1.0 };
+    if constexpr (EARLY_PARAMS) spw = stage_params_early(params, n_types);
     if (active) {
         episode = eis[FD_EI_EPISODE * n + i];
 #pragma unroll
@@ -725,7 +729,8 @@ rate_env_step_kernel(S* __restrict__ xs, typename EnvOf<S, T>::type* __restrict_
         env_load<E>(e, es, n, i, uses_sched);
         if (pre_drawn) device_reset_record<S>(seed, uint32_t(i), uint32_t(episode), ec, rec_pre);
     }
-    stage_params_finish<sizeof(T) == 4>(s_params, spw, n_types);
+    if constexpr (EARLY_PARAMS) stage_params_finish<true>(s_params, spw, n_types);
+    else stage_params<false>(s_params, params, n_types);
     if (pid_mode) {
         stage(s_pid_cfg, pid_cfg, 3 * FD_NPC);
         for (int k = threadIdx.x; k < FD_NC; k += blockDim.x) s_consts[k] = S(casc_consts[k]);
