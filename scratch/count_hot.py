@@ -28,7 +28,17 @@ valu = sum(n for k, n in c.items() if k.startswith("v_"))
 print(f"{want}: loop lines {i}..{j}, VALU {valu}, scalar {sum(n for k, n in c.items() if k.startswith('s_'))}")
 print("  pk:", {k: n for k, n in c.items() if k.startswith("v_pk")})
 print("  top:", c.most_common(12))
-m = re.search(r"\.vgpr_count:\s+(\d+)", "\n".join(lines[end:end + 3000]))
+# every instantiation's private segment and register count, straight from the kernel descriptors: a change made for the benched
+# build must not leave scratch behind in another one (it did once: a dead 20-byte segment in the f64 env kernel)
+name = None
 for l in lines:
-    if want in l and ".name:" in l:
-        pass
+    m = re.match(r"\s*\.amdhsa_kernel (\S+)", l)
+    if m:
+        name = m.group(1)
+    elif name and ".amdhsa_private_segment_fixed_size" in l:
+        priv = int(l.split()[-1])
+    elif name and ".amdhsa_next_free_vgpr" in l:
+        short = re.sub(r"E+v?i?PT_.*", "", name)
+        if any(k in short for k in ("rate_env_step", "sixdof_step", "cascade_step", "agent_step")):
+            print(f"  {short:42s} private segment {priv:4d} B   vgpr {int(l.split()[-1])}")
+        name = None
