@@ -1086,7 +1086,10 @@ FD_DEFINE_CASCADE(fdyn_cascade_step_f32, float, float)
         if (pool && pool_depth < 1) return FDYN_ERR_BAD_SIZE;                                                \
         if ((!actions || residual_scale > 0.0f) && !(pid_state && pid_cfg && casc_consts)) return FDYN_ERR_NULL; \
         if (!obs_out || !terminated || !truncated || !env_consts) return FDYN_ERR_NULL;                      \
-        if (ev_count && (!ev_int || !ev_flt || ev_cap < 0)) return FDYN_ERR_NULL;                            \
+        if (ev_count && (!ev_int || !ev_flt)) return FDYN_ERR_NULL;                                          \
+        /* records go to FD_EV_SHARDS equal segments: a capacity that is not a positive multiple would give   \
+           segments of zero (or fewer than stated) records and drop episode ends silently */                  \
+        if (ev_count && (ev_cap < FD_EV_SHARDS || ev_cap % FD_EV_SHARDS != 0)) return FDYN_ERR_BAD_SIZE;       \
         if (sizeof(T) == 4 && n > int64_t(simd_count()) * FD_WAVE)   /* more than one wave per SIMD */            \
             hipLaunchKernelGGL((rate_env_step_kernel<S, T, true>), dim3(grid_for(n)), dim3(FD_BLOCK), 0, (hipStream_t)stream, \
                            x, e, ei, type, params, n_types, env_consts, actions, pid_state, pid_cfg,         \

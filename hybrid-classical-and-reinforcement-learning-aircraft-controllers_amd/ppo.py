@@ -249,7 +249,7 @@ class RecurrentPPO:
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src)                                # un-fused policy paths return fresh tensors
             self._cur = 1 - self._cur
-            if fused_glue and term.dtype == torch.uint8:
+            if fused_glue:                                        # any flag dtype: its tensor-op fallback bumps the counter too
                 episode_flags(term, trunc, self.episode_start, self.keep, counter)
             else:
                 self.episode_start.copy_((term | trunc).float())

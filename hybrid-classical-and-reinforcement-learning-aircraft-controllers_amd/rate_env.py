@@ -54,7 +54,11 @@ class GpuRateVecEnv:
         self.truncated = torch.zeros(n, dtype=torch.uint8, device=dev)
         self.actions_taken = torch.zeros((n, L.FD_ACT_DIM), dtype=torch.float32, device=dev)
         # compacted episode-end records: FD_EV_SHARDS segments, one counter each (one fleet-wide atomic word saturates)
-        self.ev_cap = int(event_capacity if event_capacity is not None else self.lib.fdyn_event_capacity(n))
+        full = int(self.lib.fdyn_event_capacity(n))
+        if event_capacity is None:
+            self.ev_cap = full
+        else:                                    # a caller's figure: whole shards (the kernel divides it by FD_EV_SHARDS), at most `full`
+            self.ev_cap = min(full, -(-max(int(event_capacity), 1) // L.FD_EV_SHARDS) * L.FD_EV_SHARDS)
         self._ev_cap_shard = self.ev_cap // L.FD_EV_SHARDS
         self._ev_counts = torch.zeros((2, L.FD_EV_SHARDS), dtype=torch.int32, device=dev)   # ping-pong sets (kernel clears the other)
         self._ev_slot = 0

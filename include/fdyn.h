@@ -137,7 +137,8 @@ int fdyn_agent_step_f32(int level, float* x, float* pid_state, const uint8_t* ty
  *        reward_f32 [n] / reward_full [n] (either may be NULL) ; terminated, truncated [n] uint8
  *        ev_count [FD_EV_SHARDS] int32 (must be 0 on entry), ev_int [ev_cap][FD_EV_NI], ev_flt [ev_cap][FD_EV_NF]:
  *        compacted episode-end records (env id, length, terminated | return, terminal observation) in FD_EV_SHARDS
- *        segments of ev_cap / FD_EV_SHARDS records (fdyn_layout.h); NULL = no records.
+ *        segments of ev_cap / FD_EV_SHARDS records (fdyn_layout.h); NULL = no records.  ev_cap must be a positive
+ *        multiple of FD_EV_SHARDS (FDYN_ERR_BAD_SIZE otherwise); fdyn_event_capacity(n) never drops a record.
  *        ev_count_next [FD_EV_SHARDS] or NULL: a second counter set this launch clears, so two sets can be
  *        ping-ponged across steps without a memset on the stream                                              */
 #define FDYN_DECLARE_ENV(SUFFIX, S, E)                                                                          \

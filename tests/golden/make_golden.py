@@ -540,7 +540,11 @@ class RefComposedRateEnv:
         pe, qe, re = c[0] - s.p, c[1] - s.q, c[2] - s.r
         reward, comps = self.reward_tracker.compute(pe, qe, re, action, self.prev_action, s.airspeed,
                                                     s.altitude, s.roll, s.pitch)
-        reward += self.settle_bonus.compute(pe, qe, re, c[0], c[1], c[2], self.dt)
+        settle = self.settle_bonus.compute(pe, qe, re, c[0], c[1], c[2], self.dt)
+        reward += settle
+        # what rate_env.py:276-279,421-433 hands out as info["reward_components"] / accumulates in episode_rewards
+        self.last_components = np.array([comps["tracking"], comps["smoothness"], comps["stability"], comps["oscillation"],
+                                         comps["survival"], settle])
         self.prev_action = action.copy()
         terminated = bool(s.altitude < 5.0 or abs(s.roll) > np.radians(120) or abs(s.pitch) > np.radians(80)
                           or s.airspeed < 8.0)
@@ -554,7 +558,7 @@ def run_env_episode(env, policy, reset_seed, max_steps=600):
     obs = [env.reset(seed=reset_seed)]
     cmd0 = env.rate_command.copy()
     x0 = state_vec(env.sim._physics)
-    acts, rews, flags, cmds, xs = [], [], [], [], []
+    acts, rews, flags, cmds, xs, comps = [], [], [], [], [], []
     pid = None
     for k in range(max_steps):
         if isinstance(policy, np.ndarray):
@@ -574,10 +578,12 @@ def run_env_episode(env, policy, reset_seed, max_steps=600):
         flags.append([term, trunc, settled])
         cmds.append(env.rate_command.copy())
         xs.append(state_vec(env.sim._physics))
+        comps.append(env.last_components.copy())
         if term or trunc:
             break
+    # reward_components [T][6]: the reference tracker's tracking / smoothness / stability / oscillation / survival + the settle bonus
     return dict(x0=x0, cmd0=cmd0, obs=np.array(obs), actions=np.array(acts), rewards=np.array(rews),
-                flags=np.array(flags), cmds=np.array(cmds), states=np.array(xs))
+                flags=np.array(flags), cmds=np.array(cmds), states=np.array(xs), reward_components=np.array(comps))
 
 
 def gen_env():

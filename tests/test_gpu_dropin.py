@@ -106,17 +106,64 @@ def test_gym_env_reproduces_survey_episode():
     assert np.allclose(obs[9:14], [20.6181, 192.6071, 0.1214717, 0.05165746, 0.980294], rtol=1e-6)
     assert set(info) >= {"time", "step", "position", "rate_command", "rate_error", "airspeed", "altitude", "is_settled"}
     total, k = 0.0, 0
+    names = ("tracking", "smoothness", "stability", "oscillation", "survival", "settle_bonus")
+    assert set(env.episode_rewards) == set(names) | {"crash_penalty"}            # rate_env.py:141-149
     while True:
         obs, r, term, trunc, info = env.step(np.array([0.1, 0.0, 0.0, 0.6], dtype=np.float32))
+        # info["reward_components"] (rate_env.py:276-279,421-433) against the reference tracker's own per-step components
+        c = info["reward_components"]
+        assert np.allclose([c[n] for n in names], g["reward_components"][k], rtol=1e-12, atol=1e-13), (k, c)
+        assert abs(c["total"] - g["reward_components"][k, :5].sum()) < 1e-12 and c["tracking_error_mse"] >= 0.0
+        assert abs(c["total"] + c["settle_bonus"] + c.get("crash_penalty", 0.0) - r) < 1e-9
         total += r
         k += 1
         if term or trunc:
             break
+        prev_c = c
     assert k == 150 and term and not trunc and abs(total + 15.188049) < 1e-5
+    assert c["crash_penalty"] == -100.0 and "crash_penalty" not in prev_c          # only on the crashing step (:289-294)
+    for j, n in enumerate(names):                                                  # per-component episode sums (:276-279)
+        assert abs(env.episode_rewards[n] - g["reward_components"][:, j].sum()) < 1e-9, n
+    assert env.episode_rewards["crash_penalty"] == 0.0                             # the reference never adds to it
     st = env.sim.get_state()
     assert abs(st.altitude - info["altitude"]) < 1e-9
     obs2, _ = env.reset()                                         # next episode continues the sampler streams
     assert rel_err(obs2, obs).max() > 1e-3
+
+
+@pytest.mark.gpu
+def test_gym_env_reward_components_with_fp32_env_words():
+    """The same per-step components from the `mixed` build, whose env words are fp32 and whose settle-timer word counts steps
+    (the scorer is fed the count with dt = 1 and the count threshold): 1e-5 of the reference's, settle bonus on the same steps."""
+    from hcrl_amd.gym_env import RateControlEnv
+    g = load_golden("env_medium_step_seed11_pid.npz")
+    env = RateControlEnv(difficulty="medium", command_type="step", rng_seed=11, precision="mixed")
+    env.reset(seed=11)
+    names = ("tracking", "smoothness", "stability", "oscillation", "survival", "settle_bonus")
+    T = len(g["ep0_rewards"])
+    for k in range(T):
+        _, r, term, trunc, info = env.step(g["ep0_actions"][k])
+        c = info["reward_components"]
+        assert np.allclose([c[n] for n in names], g["ep0_reward_components"][k], rtol=2e-5, atol=2e-5), (k, c, g["ep0_reward_components"][k])
+    assert term or trunc
+    # no reference episode settles (the default PID limit-cycles), so the bonus path is driven by hand: the command follows the
+    # aircraft's own rates, the error stays under the 0.05 rad/s threshold, and both builds must pay 2 dt from the same step on
+    import torch
+    from hcrl_amd import layout as L
+    envs = [RateControlEnv(difficulty="easy", command_type="step", rng_seed=3, precision=p) for p in ("f64", "mixed")]
+    bonus = []
+    for e in envs:
+        e.reset(seed=3)
+        row = []
+        for k in range(30):
+            v = e._vec
+            v.e[L.FD_E_CMD_P:L.FD_E_CMD_R + 1, 0] = v.x[9:12, 0].to(v.e.dtype)
+            _, _, term, trunc, info = e.step(np.array([0.0, 0.0, 0.0, 0.6], dtype=np.float32))
+            row.append(info["reward_components"]["settle_bonus"])
+        bonus.append(row)
+        assert abs(e.episode_rewards["settle_bonus"] - sum(row)) < 1e-12
+    assert bonus[0] == pytest.approx(bonus[1], abs=1e-9) and max(bonus[0]) == pytest.approx(0.04) and bonus[0][5] == 0.0
+    assert np.nonzero(bonus[0])[0][0] in (9, 10)                       # 0.2 s of 0.02 s steps (the float sum crosses at the 10th / 11th)
 
 
 @pytest.mark.gpu

@@ -1,22 +1,41 @@
-"""GPU parity at the HEADLINE batch: every one of 65 536 distinct aircraft / envs of one launch against the on-box CPU oracle.
+"""GPU parity at the HEADLINE batch: every one of 65 536 distinct aircraft / envs of one launch against the on-box CPU oracle,
+gated PER AIRCRAFT (round 3; the round-2 form allowed N // 2000 unexplained outliers and N // 500 lost envs unconditionally).
 
 test_gpu_parity_scale.py characterises 4096 distinct aircraft in depth (amplification, the fp32 floor, the reference's own
 guards).  BASELINE.json quotes its metric at batch 65 536; the oracle (OpenMP) flies that many aircraft for 1000 RK4 steps in a
 few seconds on the box's host cores, so the full batch is compared directly, not through tiling or properties:
 
   * cfg 2 (SURVEY §8d recipe, its own seed): 65 536 distinct initial conditions and control settings, 1000 steps at dt = 1 ms
-    (one second of flight, the env's sub-step), `mixed` and `f64` against `orc_sixdof_step_batch`;
+    (one second of flight, the env's sub-step), `mixed` and `f64` against `orc_sixdof_step_batch`, beside the oracle's own
+    1e-12-perturbed twins (amplification) and a per-step mask of the reference's guards (simplified_6dof.py:258-291,364-376);
   * the env: 65 536 parity-sampled envs x 120 steps of 2 s episodes (so every surviving env is truncated at step 100 and
     auto-resets; ~0.2 % of the env-steps carry a saturating action and crash some earlier) against `orc_env_step_batch` +
-    `orc_env_reset`: done flags, rewards, states.
+    `orc_env_reset`, beside the oracle's own 1e-7-perturbed copy: done flags, rewards, states.
+
+The gates: the north-star 1e-4 on EVERY aircraft the reference model itself reproduces -- amplification of a 1e-12 input
+perturbation <= 1e3 (beyond that the reference does not reproduce itself: tests/test_oracle_scale.py) AND no jump of the oracle's
+own twins under an fp32-sized (1e-7 .. 1e-6) perturbation; every other aircraft is bounded by what the oracle's own twins do
+(smooth growth: error <= 2e-6 x amplification; a jump: error <= 2 x the twins' own jump); no env lost to a done-flag mismatch
+unless the oracle loses its own perturbed copy there too.  Every aircraft over the gate is listed (index, component,
+amplification, twins' worst error, guards touched) on stdout and in gpurun_out/full_batch_outliers.json.
+
+The jump (found in round 3 on the two "well-conditioned" outliers of the round-2 log): in BACKWARD flight (u < 0) the angle of
+attack atan2(w, u_safe) (simplified_6dof.py:368-370) sits at +-pi and is clipped to +-max_alpha, so C_L jumps by
+cl_alpha x 60 deg when w crosses zero; an RK4 stage that lands within rounding of w = 0 takes the other branch, and the
+trajectory is displaced by one stage's worth of that jump (5e-3 .. 8e-3 relative on u / w).  The fp64 oracle does exactly this
+to its own 1e-7-perturbed twin -- same aircraft, same 7.90e-3 / 5.18e-3 -- so it is a discontinuity of the reference model, not
+an fp32 defect of the asin kind.
 
 Percentiles go to stdout and to gpurun_out/drift.json under "*_full_batch" keys.
 """
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err, STATE_ANGLE_COLS
+from conftest import REPO, rel_err, STATE_ANGLE_COLS
 from hcrl_amd import layout as L, samplers
 from hcrl_amd.fleet import BatchedSixDOF
 from hcrl_amd.params import AircraftParams
@@ -26,70 +45,168 @@ from test_gpu_parity_scale import _cfg2_inputs, _env_actions, _OracleFleet, _rec
 pytestmark = pytest.mark.gpu
 
 N = 65536
+STATE_NAMES = ("N", "E", "D", "u", "v", "w", "roll", "pitch", "yaw", "p", "q", "r")
+# simplified_6dof.py:368,370,268/463,273,262,276; "backward_w0" = w changes sign while u < 0 (the alpha clip flips sign there)
+GUARDS = ("u_safe", "alpha_clip", "pitch_clamp", "rate_clamp", "vel_clamp", "ground", "backward_w0")
+TWIN_PERTURBATIONS = (1e-7, 1e-7, 1e-7, 1e-7, 3e-7, 3e-7, 3e-7, 3e-7, 1e-6, 1e-6, 1e-6, 1e-6)   # "fp32-sized": the mixed path's own p50 .. p99.9
+_ORACLE = {}
+
+
+def _guard_bits(base, P):
+    """Which of the reference's guards each aircraft is ON (not merely near) after a step -- bit i = GUARDS[i]."""
+    min_u, max_alpha, max_pitch, max_rate, max_vel = (P[L.FD_P_MIN_U_VELOCITY], P[L.FD_P_MAX_ALPHA_RAD], P[L.FD_P_MAX_PITCH_RAD],
+                                                      P[L.FD_P_MAX_RATE_RAD], P[L.FD_P_MAX_VELOCITY])
+    alpha = np.arctan2(base[5], np.where(np.abs(base[3]) < min_u, np.where(base[3] >= 0, min_u, -min_u), base[3]))
+    g = (np.abs(base[3]) < min_u).astype(np.int32)
+    g |= (np.abs(alpha) >= max_alpha).astype(np.int32) << 1
+    g |= (np.abs(base[7]) >= max_pitch * (1 - 1e-12)).astype(np.int32) << 2
+    g |= (np.abs(base[9:12]).max(0) >= max_rate * (1 - 1e-12)).astype(np.int32) << 3
+    g |= (np.abs(base[3:6]).max(0) >= max_vel * (1 - 1e-12)).astype(np.int32) << 4
+    g |= (-base[2] <= 0.0).astype(np.int32) << 5
+    return g
+
+
+def _oracle_cfg2_full(oracle, dt=0.001, steps=1000, chunk=100):
+    """Oracle trajectory checkpoints every `chunk` steps; its amplification of a 1e-12 relative perturbation of the initial
+    state (three sign patterns, worst over the checkpoints, / 1e-12); `lost` = the worst error of its own twins under
+    fp32-sized perturbations (TWIN_PERTURBATIONS, random signs); the union of the guards each aircraft touched."""
+    if "cfg2" in _ORACLE:
+        return _ORACLE["cfg2"]
+    x0, u = _cfg2_inputs(N, seed=20261005)
+    P = AircraftParams().to_block()
+    us = np.ascontiguousarray(u.T)
+    threads = min(16, int(oracle.lib.orc_max_threads()))
+    step = lambda arr, k: oracle.lib.orc_sixdof_step_batch(oracle.dp(P), oracle.dp(arr), oracle.dp(us), N, dt * k, k, threads)  # noqa: E731
+    rs = np.random.RandomState(1)
+    base = np.ascontiguousarray(x0.T)
+    twins = [np.ascontiguousarray((x0 * (1 + 1e-12 * rs.choice([-1.0, 1.0], x0.shape))).T) for _ in range(3)]
+    big = [np.ascontiguousarray((x0 * (1 + eps * rs.choice([-1.0, 1.0], x0.shape))).T) for eps in TWIN_PERTURBATIONS]
+    traj, amp, lost, guards = [], np.zeros(N), np.zeros(N), np.zeros(N, np.int32)
+    for k in range(steps):
+        w_prev = base[5].copy()
+        step(base, 1)
+        guards |= _guard_bits(base, P)
+        guards |= ((base[3] < 0) & (np.sign(base[5]) != np.sign(w_prev))).astype(np.int32) << 6
+        if k % chunk == chunk - 1:
+            traj.append(base.T.copy())
+            for b in twins:
+                step(b, chunk)
+                amp = np.maximum(amp, rel_err(b.T, base.T, STATE_ANGLE_COLS).max(1) / 1e-12)
+            for b in big:
+                step(b, chunk)
+                lost = np.maximum(lost, rel_err(b.T, base.T, STATE_ANGLE_COLS).max(1))
+    _ORACLE["cfg2"] = (x0, u, traj, amp, lost, guards)
+    return _ORACLE["cfg2"]
+
+
+def _dump_outliers(tag, idx, worst, comp, amp, lost, guards, x0, u):
+    rows = [{"aircraft": int(i), "worst_rel_err": float(worst[i]), "component": STATE_NAMES[int(comp[i])],
+             "amplification": float(amp[i]), "oracle_twins_worst": float(lost[i]), "guards": [g for b, g in enumerate(GUARDS) if guards[i] >> b & 1],
+             "x0": [float(v) for v in x0[i]], "controls": [float(v) for v in u[i]]} for i in idx]
+    out = os.path.join(REPO, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, "full_batch_outliers.json")
+    doc = json.load(open(path)) if os.path.exists(path) else {}
+    doc[tag] = rows
+    with open(path, "w") as f:
+        json.dump(doc, f, indent=1)
+    for r in rows:
+        print(f"   aircraft {r['aircraft']:6d}: {r['worst_rel_err']:.2e} on {r['component']:5s} amplification {r['amplification']:.2e} "
+              f"oracle's own fp32-sized twins {r['oracle_twins_worst']:.2e} guards {','.join(r['guards']) or '-'}")
 
 
 @pytest.mark.parametrize("precision", ["f64", "mixed"])
 def test_cfg2_65536_distinct_aircraft_1000_steps_vs_oracle(oracle, precision):
-    """The north-star gate (1e-4 relative over 1000 steps) on a whole headline-size launch.  A handful of the 65 536 aircraft
-    tumble through the u ~ 0 sign switch or sit on a clamp within the second (where the reference does not reproduce itself,
-    tests/test_oracle_scale.py), so the gate is asserted on the distribution -- p99.9 -- and the count beyond it is bounded and
-    reported; the 4096-aircraft test holds the per-aircraft analysis."""
+    """The north-star gate (1e-4 relative over 1000 steps) on a whole headline-size launch, per aircraft: every aircraft the
+    reference model itself reproduces (amplification of a 1e-12 input perturbation <= 1e3, and its own fp32-sized twins do not
+    jump) is inside the gate; every other aircraft stays within what the oracle's own twins do (module docstring)."""
     dt, steps, chunk = 0.001, 1000, 100
-    x0, u = _cfg2_inputs(N, seed=20261005)
-    P = AircraftParams().to_block()
-    us, base = np.ascontiguousarray(u.T), np.ascontiguousarray(x0.T)
-    threads = min(16, int(oracle.lib.orc_max_threads()))
+    x0, u, traj, amp, lost, guards = _oracle_cfg2_full(oracle, dt, steps, chunk)
     fl = BatchedSixDOF(N, precision)
     fl.reset(x0)
     fl.set_controls(u)
-    worst = np.zeros(N)
-    for _ in range(steps // chunk):
-        oracle.lib.orc_sixdof_step_batch(oracle.dp(P), oracle.dp(base), oracle.dp(us), N, dt * chunk, chunk, threads)
+    worst, comp = np.zeros(N), np.zeros(N, np.int64)
+    for k in range(steps // chunk):
         for _ in range(chunk):
             fl.step(dt)
-        worst = np.maximum(worst, rel_err(fl.state_numpy(), base.T, STATE_ANGLE_COLS).max(1))
+        e = rel_err(fl.state_numpy(), traj[k], STATE_ANGLE_COLS)
+        comp = np.where(e.max(1) > worst, e.argmax(1), comp)
+        worst = np.maximum(worst, e.max(1))
     gate = 1e-4 if precision == "mixed" else 1e-9
-    over = int((worst > gate).sum())
-    q = _record(precision, "cfg2_dt0.001_1000_steps_full_batch", worst, **{"p99.9": float(np.percentile(worst, 99.9)), "n_over_gate": over})
+    unit = 2e-6 if precision == "mixed" else 1e-10       # error per unit of smooth amplification: ~30 fp32 ulps / ~1e-10 (as at 4096)
+    smooth = 3.0 * max(TWIN_PERTURBATIONS) * np.maximum(amp, 1.0)        # what smooth growth makes of the largest twin perturbation
+    jumps = lost > np.maximum(10.0 * smooth, 1e-4)                       # the reference's own twins take another branch
+    well = (amp <= 1e3) & ~jumps
+    over = np.nonzero(worst > gate)[0]
+    ratio = worst / np.maximum(amp, 1.0)
+    bound = np.where(well, gate, np.where(jumps, np.maximum(2.0 * lost, gate), unit * np.maximum(amp, 1.0)))
+    q = _record(precision, "cfg2_dt0.001_1000_steps_full_batch", worst, **{
+        "p99.9": float(np.percentile(worst, 99.9)), "n_over_gate": int(over.size), "n_reproducible": int(well.sum()),
+        "max_where_reproducible": float(worst[well].max()), "n_amp_gt_1e3": int((amp > 1e3).sum()),
+        "n_oracle_twins_jump": int(jumps.sum()), "err_over_amp_max_where_no_jump": float(ratio[~jumps].max()),
+        "n_on_a_guard": int((guards != 0).sum()), "n_over_gate_reproducible": int((worst[well] > gate).sum()),
+        "n_over_its_bound": int((worst > bound).sum())})
     print(f"\n[drift@full batch] cfg2 {precision} dt=1 ms: {N} distinct aircraft x {steps} steps vs oracle: p50 {q['p50']:.2e} "
-          f"p99 {q['p99']:.2e} p99.9 {q['p99.9']:.2e} max {q['max']:.2e}; {over} aircraft over {gate:g}")
+          f"p99 {q['p99']:.2e} p99.9 {q['p99.9']:.2e} max {q['max']:.2e}; {over.size} aircraft over {gate:g}\n"
+          f"   reproducible by the reference model itself: {int(well.sum())} aircraft (amplification > 1e3 on {int((amp > 1e3).sum())}, "
+          f"the oracle's own fp32-sized twins jump on {int(jumps.sum())}), max there {q['max_where_reproducible']:.2e}; "
+          f"error / amplification max {ratio[~jumps].max():.2e} off the jumps; {int((guards != 0).sum())} aircraft touched a guard")
+    show = over if over.size else np.argsort(worst)[-5:]
+    _dump_outliers(f"cfg2_{precision}", show[np.argsort(-worst[show])][:32], worst, comp, amp, lost, guards, x0, u)
     assert np.isfinite(worst).all()
-    assert q["p99.9"] <= gate and over <= N // 2000, q
+    assert well.sum() >= 0.995 * N, int(well.sum())     # one second at 1 ms: the fleet is still overwhelmingly reproducible
+    assert worst[well].max() <= gate, (float(worst[well].max()), int(np.argmax(np.where(well, worst, 0))))      # THE gate, per aircraft
+    bad = np.nonzero(worst > bound)[0]                   # the rest: no worse than the reference model is to itself
+    assert bad.size == 0, [(int(i), float(worst[i]), float(amp[i]), float(lost[i])) for i in bad[:8]]
 
 
 def test_env_65536_envs_120_steps_with_auto_reset_vs_oracle(oracle):
     """One headline-size env fleet, `mixed`, every env against the oracle: done flags (an env leaves the comparison at its first
-    mismatch -- different episodes afterwards), rewards and states."""
+    mismatch -- different episodes afterwards), rewards and states, conditioned on the oracle's own 1e-7-perturbed copy exactly
+    as the 4096-env test is: no env lost where the oracle keeps its copy, 1e-4 wherever the copy stays within 1e-5."""
     precision, steps, depth = "mixed", 120, 2          # depth: the host MT19937 pool costs ~0.2 ms per record; both sides wrap modulo depth
     env = GpuRateVecEnv(N, "medium", 2.0, 0.02, "step", seed=1977, precision=precision, sampling="parity", pool_depth=depth)
     pool = env.pool.cpu().numpy()
     P, EC = AircraftParams().to_block(), samplers.env_consts("medium", 2.0, 0.02, "step")
     obs_g = env.reset().cpu().numpy()
-    ref = _OracleFleet(oracle, pool, P, EC)
+    ref, per = _OracleFleet(oracle, pool, P, EC), _OracleFleet(oracle, pool, P, EC, perturb=1e-7)
     assert rel_err(obs_g, ref.obs).max() < 1e-6
     acts = _env_actions(N, steps, seed=6)
-    alive = np.ones(N, bool)
-    worst_state, worst_rew = np.zeros(N), np.zeros(N)
+    alive, alive7 = np.ones(N, bool), np.ones(N, bool)
+    worst_state, worst_rew, d7 = np.zeros(N), np.zeros(N), np.zeros(N)
     n_done = 0
     for k in range(steps):
         a = acts[k]
         _obs, _r, term, trunc = env.step_device(torch.as_tensor(a, device=env.device))
         te, tr = ref.step(a)
+        te7, tr7 = per.step(a)
         n_done += int((te | tr).sum())
         alive &= (term.cpu().numpy().astype(bool) == te) & (trunc.cpu().numpy().astype(bool) == tr)
+        alive7 &= (te7 == te) & (tr7 == tr)
         rg = env.rewards_full.to(torch.float64).cpu().numpy()
         worst_rew = np.maximum(worst_rew, np.where(alive, np.abs(rg - ref.rew) / np.maximum(np.abs(ref.rew), 1.0), 0.0))
         if k % 20 == 19:
             sg = env.x.to(torch.float64).T.cpu().numpy()
             worst_state = np.maximum(worst_state, np.where(alive, rel_err(sg, ref.xs.T, STATE_ANGLE_COLS).max(1), 0.0))
-    lost = int((~alive).sum())
+            d7 = np.maximum(d7, np.where(alive7, rel_err(per.xs.T, ref.xs.T, STATE_ANGLE_COLS).max(1), 1.0))
+    d7 = np.where(alive7, d7, 1.0)
+    lost, lost_kept = int((~alive).sum()), int((~alive & alive7).sum())
+    well7 = d7 <= 1e-5
+    ratio = worst_state / np.maximum(d7, 1e-6)
     over = int((worst_state[alive] > 1e-4).sum())
-    qs = _record(precision, "env_120_steps_state_full_batch", worst_state[alive], flag_mismatch_envs=lost, episode_ends=n_done,
-                 n_over_gate=over, **{"p99.9": float(np.percentile(worst_state[alive], 99.9))})
-    qr = _record(precision, "env_120_steps_reward_full_batch", worst_rew[alive])
+    qs = _record(precision, "env_120_steps_state_full_batch", worst_state[alive], flag_mismatch_envs=lost,
+                 flag_mismatch_envs_where_oracle_keeps_its_copy=lost_kept, oracle_lost_its_perturbed_copy=int((~alive7).sum()),
+                 episode_ends=n_done, n_over_gate=over, n_d7_le_1e5=int(well7.sum()),
+                 max_where_d7_le_1e5=float(worst_state[well7 & alive].max()), err_over_d7_max=float(ratio[alive].max()),
+                 **{"p99.9": float(np.percentile(worst_state[alive], 99.9))})
+    qr = _record(precision, "env_120_steps_reward_full_batch", worst_rew[alive], max_where_d7_le_1e5=float(worst_rew[well7 & alive].max()))
     print(f"\n[drift@full batch] env {precision}: {N} envs x {steps} steps ({n_done} episode ends, auto-reset), {lost} envs left the "
-          f"comparison at a done-flag mismatch\n   state  p50 {qs['p50']:.2e} p99 {qs['p99']:.2e} p99.9 {qs['p99.9']:.2e} max {qs['max']:.2e} "
-          f"({over} over 1e-4)\n   reward p50 {qr['p50']:.2e} p99 {qr['p99']:.2e} max {qr['max']:.2e}")
+          f"comparison at a done-flag mismatch ({lost_kept} of them where the oracle keeps its own 1e-7-perturbed copy; the oracle "
+          f"loses {int((~alive7).sum())})\n   state  p50 {qs['p50']:.2e} p99 {qs['p99']:.2e} p99.9 {qs['p99.9']:.2e} max {qs['max']:.2e} "
+          f"({over} over 1e-4); d7 <= 1e-5 on {int(well7.sum())} envs, max there {qs['max_where_d7_le_1e5']:.2e}; "
+          f"err / max(d7, 1e-6) max {qs['err_over_d7_max']:.1f}\n   reward p50 {qr['p50']:.2e} p99 {qr['p99']:.2e} max {qr['max']:.2e}")
     assert n_done > N                                  # every env was truncated at step 100 at the latest
-    assert lost <= N // 500, lost
-    assert qs["p99.9"] <= 1e-4 and over <= N // 2000 and np.percentile(worst_rew[alive], 99.9) <= 1e-4
+    assert lost_kept == 0, lost_kept                   # a lost env is one the oracle loses too
+    assert lost <= 2 * int((~alive7).sum()) + 2, (lost, int((~alive7).sum()))
+    assert worst_state[well7 & alive].max() <= 1e-4 and ratio[alive].max() <= 30.0
+    assert worst_rew[well7 & alive].max() <= 1e-4
