@@ -40,6 +40,10 @@ def main(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend under torch.distributed.run (nccl = RCCL over xGMI; gloo for rehearsals)")
     ap.add_argument("--device-index", type=int, default=-1, help="force every rank onto this GPU (one-GPU rehearsal of N > 1)")
+    ap.add_argument("--rank-report", type=str, default=None, metavar="DIR",
+                    help="every rank writes DIR/rank<r>.json at the end: digests of its parameters and of its env shard's first "
+                         "observations, its env seed, whether the rollout / update graphs ran (what a data-parallel run must "
+                         "agree and differ on)")
     args = ap.parse_args(argv)
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs between ranks on this driver stack
@@ -76,6 +80,7 @@ def main(argv=None):
                             compute_dtype=torch.bfloat16 if args.bf16 else None)
     env = create_vec_env(config, n_envs=n_envs, seed=seed + rank * n_envs, precision=args.precision)
     model = RecurrentPPO(env, policy, PPOConfig.from_dict(config["ppo"]), seed=seed)
+    first_obs = model.obs.detach().cpu().numpy().tobytes() if args.rank_report else None
 
     if args.resume:
         model.load(args.resume)
@@ -131,6 +136,20 @@ def main(argv=None):
                                      command_type=config["environment"]["command_type"])
         print(f"final evaluation ({config['environment']['difficulty']}/{config['environment']['command_type']}):",
               {k: v for k, v in final.items() if k.startswith("mean")})
+    if args.rank_report:
+        import hashlib
+        import json
+        os.makedirs(args.rank_report, exist_ok=True)
+        h = hashlib.sha256()
+        for name, t in sorted(model.policy.state_dict().items()):
+            h.update(name.encode())
+            h.update(t.detach().cpu().contiguous().numpy().tobytes())
+        rep = {"rank": rank, "world": world, "param_sha256": h.hexdigest(), "env_seed": seed + rank * n_envs,
+               "first_obs_sha256": hashlib.sha256(first_obs).hexdigest(), "num_timesteps": int(model.num_timesteps),
+               "rollout_graph": model._graph is not None, "update_graph": getattr(model, "_update_graph", None) is not None,
+               "collective_backend": (args.backend if world > 1 else None), "device_index": dev_index}
+        with open(os.path.join(args.rank_report, f"rank{rank}.json"), "w") as f:
+            json.dump(rep, f)
     if world > 1:
         dist.destroy_process_group()
 
