@@ -110,6 +110,59 @@ def pack_fe_weights(w_emb, w1, w2, w_proj):
     return torch.cat(parts).contiguous()
 
 
+# ---- csrc/policy_rc64.hip: both recurrent cells in one launch, lane = batch row ---------------------------------------------
+# The kernel keeps activations and state in its own layouts (whole 1 KB wave accesses, a lane touches only its own row).  Row
+# 64 wb + 32 t + r lives in lane r + 32 hf of wave-block wb, tile t; hidden unit n = 32 sl + 16 hq + 8 p2 + 4 hf + p01.
+def _kperm(K, device):
+    return torch.tensor([16 * (k // 16) + _KPERM16[k % 16] for k in range(K)], device=device)
+
+
+def rc_pack_x(x):
+    """[B][16 S] row-major activations -> B fragments [B/64][2][S][64][8] bf16 (S k-steps; features 128: S = 8, h 256: S = 16),
+    returned with the row-major shape."""
+    B, K = x.shape
+    return (x.to(torch.bfloat16).reshape(B // 64, 2, 32, K // 32, 2, 2, 2, 4).permute(0, 1, 3, 4, 6, 2, 5, 7)
+            .contiguous().view(B, K))
+
+
+def rc_unpack_x(xi):
+    B, K = xi.shape
+    return xi.reshape(B // 64, 2, K // 32, 2, 2, 32, 2, 4).permute(0, 1, 5, 2, 3, 6, 4, 7).contiguous().view(B, K)
+
+
+rc_pack_h, rc_unpack_h = rc_pack_x, rc_unpack_x
+
+
+def rc_pack_c(c):
+    """[B][256] fp32 cell state -> [B/64][slice 8][tile 2][group 4][lane 64][4] fp32."""
+    B, Hh = c.shape
+    return c.float().reshape(B // 64, 2, 32, Hh // 32, 4, 2, 4).permute(0, 3, 1, 4, 5, 2, 6).contiguous().view(B, Hh)
+
+
+def rc_unpack_c(ci):
+    B, Hh = ci.shape
+    return ci.reshape(B // 64, Hh // 32, 2, 4, 2, 32, 4).permute(0, 2, 5, 1, 3, 4, 6).contiguous().view(B, Hh)
+
+
+def pack_rc_weights(cells):
+    """[(W_ih [4H][128], W_hh [4H][256])] for the actor and the critic -> the byte image csrc/policy_rc64.hip streams through
+    LDS: per cell and 32-unit slice the rows of gates i, g, f, o (the order the kernel multiplies them in), each row
+    [W_ih | W_hh] with the k order of the activation fragments (_KPERM16) + 16 bytes of padding, each 32-row chunk padded to
+    28 KB (seven 1 KB pieces per wave)."""
+    bf = torch.bfloat16
+    parts = []
+    for w_ih, w_hh in cells:
+        dev = w_ih.device
+        w = torch.cat([w_ih.detach().float()[:, _kperm(w_ih.shape[1], dev)], w_hh.detach().float()[:, _kperm(w_hh.shape[1], dev)]], 1)
+        Hh = w.shape[0] // 4
+        for sl in range(Hh // 32):
+            for gate in (0, 2, 1, 3):
+                rows = w[gate * Hh + 32 * sl:gate * Hh + 32 * sl + 32].to(bf)
+                img = torch.cat([rows, torch.zeros(32, 8, dtype=bf, device=dev)], 1).reshape(-1)
+                parts.append(torch.cat([img, torch.zeros(28 * 512 - img.numel(), dtype=bf, device=dev)]))
+    return torch.cat(parts).contiguous()
+
+
 class LSTMFeaturesExtractor(nn.Module):
     def __init__(self, obs_dim: int = OBS_DIM, features_dim: int = 128, lstm_hidden_size: int = 256, n_lstm_layers: int = 2):
         super().__init__()
@@ -289,7 +342,7 @@ class RateLSTMPolicy(nn.Module):
                 and w.shape[0] == 4 * H, "lstm_cell_mfma operand shapes"
             # the kernel writes the new state straight into the caller's ping-pong buffers when given (no copies)
             ok = ho is not None and ho.dtype == bf and ho.shape == (B, H) and ho.is_contiguous() and co.dtype == torch.float32 \
-                and co.shape == (B, H) and co.is_contiguous() and ho.data_ptr() != hp.data_ptr() and co.data_ptr() != cp.data_ptr()
+                and co.shape == (B, H) and co.is_contiguous() and (os.environ.get("FDYN_INPLACE_STATE") == "1" or (ho.data_ptr() != hp.data_ptr() and co.data_ptr() != cp.data_ptr()))
             h = ho if ok else torch.empty((B, H), dtype=bf, device=dev)
             c = co if ok else torch.empty((B, H), dtype=torch.float32, device=dev)
             _lib.check(lib.fdyn_lstm_cell_mfma(feats.data_ptr(), feats.shape[1], hp.data_ptr(), H, cp.data_ptr(),

@@ -34,7 +34,7 @@
  *   fdyn_sensor_update_*   NoisySensorInterface.update       interfaces/sensor.py:199-243
  *   fdyn_sensor_observe    the same noise model on RateControlEnv observations (rate_env.py:374-408 layout)
  * Policy side (the reference delegates these to torch.nn.LSTM / SB3's PPO, which are not in its tree):
- *   fdyn_policy_features, fdyn_lstm_cell_mfma, fdyn_policy_trunks, fdyn_policy_heads, fdyn_gaussian_head, fdyn_episode_flags
+ *   fdyn_policy_features, fdyn_policy_recurrent, fdyn_lstm_cell_mfma, fdyn_policy_trunks, fdyn_policy_heads, fdyn_gaussian_head, fdyn_episode_flags
  *                          rollout: features extractor / LSTM cell / trunks / output heads of
  *                          learned_controllers/networks/lstm_policy.py:13-136 (+ sb3_contrib's actor / critic LSTMs)
  *   fdyn_lstm_cell_fwd/_bwd, fdyn_lstm_seq_fwd/_bwd(_bsum),      BPTT point-wise cell update and its gradient (bias sums folded in),
@@ -245,6 +245,17 @@ int fdyn_ppo_loss(const float* mean, const float* actions, const float* log_std,
 int fdyn_lstm_cell_mfma(const void* x, int kx, const void* h_prev, int kh, const float* c_prev, const float* keep,
                         const void* W, const float* bias, void* h_out, float* c_out, float* h_out_f32,
                         int64_t B, int H, void* stream);
+/* BOTH recurrent cells of the rollout policy (sb3_contrib MlpLstmPolicy's actor and critic nn.LSTM(128, 256) over the shared
+ * features; reference net sizes learned_controllers/networks/lstm_policy.py:107-136) as ONE launch with lane = batch row
+ * (csrc/policy_rc64.hip).  Operands live in the kernel's own layouts (policy.py: rc_pack_x / rc_pack_h / rc_pack_c convert from
+ * and to the row-major [B][..] form): feats_frag [B/64][2][8][64][8] bf16, h [B/64][2][16][64][8] bf16,
+ * c [B/64][8][2][4][64][4] fp32; keep [B] fp32 or NULL; weight_image = fdyn_policy_recurrent_image_bytes() bytes
+ * (policy.py: pack_rc_weights), bias [2][4H] fp32 (= b_ih + b_hh per cell, gate order i, f, g, o).  out == in updates the
+ * state IN PLACE (every lane reads and writes only its own row).  B % 256 == 0.                                          */
+int fdyn_policy_recurrent_image_bytes(void);
+int fdyn_policy_recurrent(const void* feats_frag, const float* keep, const void* weight_image, const float* bias,
+                          const void* h_pi_in, const float* c_pi_in, void* h_pi_out, float* c_pi_out,
+                          const void* h_vf_in, const float* c_vf_in, void* h_vf_out, float* c_vf_out, int64_t B, void* stream);
 /* BPTT forward of the same cell (csrc/lstm_mfma.hip, TRAIN instantiation): besides h_out / c_out it stores the ACTIVATED gates
  * act_out (bf16; kh > 0: [B][4H] = sigmoid(i), sigmoid(f), tanh(g), sigmoid(o); kh = 0, the zero-state layers of the features
  * extractor: [B][3H] = (i, g, o), c_out may be NULL) for fdyn_lstm_seq_bwd / fdyn_lstm_cell0_bwd, and -- h_next != NULL --

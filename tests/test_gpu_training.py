@@ -763,3 +763,45 @@ def test_policy_features_kernel_matches_plain_torch_fp32(B):
     finally:
         del os.environ["FDYN_NO_FE64"]
     assert (feats.float() - layerwise.float()).abs().max().item() < 3e-2 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("B,inplace", [(256, False), (1024, True), (65536, True)])
+def test_recurrent_cells_one_launch_matches_plain_torch_fp32(B, inplace):
+    """csrc/policy_rc64.hip -- actor and critic nn.LSTM(128, 256) cells in one launch, lane = batch row, state in the kernel's own
+    layouts, updated in place -- against the same cells in plain fp32 PyTorch on the bf16-rounded operands."""
+    from hcrl_amd import _lib
+    from hcrl_amd.policy import pack_rc_weights, rc_pack_c, rc_pack_h, rc_pack_x, rc_unpack_c, rc_unpack_h
+    lib = _lib.load()
+    dev, bf = torch.device("cuda"), torch.bfloat16
+    g = torch.Generator(device=dev).manual_seed(B)
+    rn = lambda *s, k=1.0: torch.randn(*s, device=dev, generator=g) * k          # noqa: E731
+    x = rn(B, 128, k=0.7).to(bf)
+    keep = (torch.rand(B, device=dev, generator=g) > 0.05).float()
+    cells, ref = [], []
+    for _ in range(2):
+        w_ih, w_hh, bias = rn(1024, 128, k=0.08).to(bf), rn(1024, 256, k=0.08).to(bf), rn(1024, k=0.3)
+        h, c = rn(B, 256, k=0.5).to(bf), rn(B, 256)
+        cells.append((w_ih, w_hh, bias, h, c))
+        gates = torch.cat([x.float(), h.float() * keep[:, None]], 1) @ torch.cat([w_ih, w_hh], 1).float().t() + bias
+        i, f, gg, o = gates.chunk(4, 1)
+        c2 = torch.sigmoid(f) * (c * keep[:, None]) + torch.sigmoid(i) * torch.tanh(gg)
+        ref.append((torch.sigmoid(o) * torch.tanh(c2), c2))
+    img = pack_rc_weights([(c_[0], c_[1]) for c_ in cells])
+    assert img.numel() * 2 == lib.fdyn_policy_recurrent_image_bytes()
+    bias = torch.stack([c_[2] for c_ in cells]).contiguous()
+    xi = rc_pack_x(x)
+    hi = [rc_pack_h(c_[3]) for c_ in cells]
+    ci = [rc_pack_c(c_[4]) for c_ in cells]
+    assert torch.equal(rc_unpack_h(hi[0]), cells[0][3]) and torch.equal(rc_unpack_c(ci[1]), cells[1][4])
+    ho = hi if inplace else [torch.empty_like(t) for t in hi]
+    co = ci if inplace else [torch.empty_like(t) for t in ci]
+    _lib.check(lib.fdyn_policy_recurrent(xi.data_ptr(), keep.data_ptr(), img.data_ptr(), bias.data_ptr(),
+                                         hi[0].data_ptr(), ci[0].data_ptr(), ho[0].data_ptr(), co[0].data_ptr(),
+                                         hi[1].data_ptr(), ci[1].data_ptr(), ho[1].data_ptr(), co[1].data_ptr(), B,
+                                         _lib.current_stream()), "policy_recurrent")
+    torch.cuda.synchronize()
+    for k in range(2):
+        h2, c2 = rc_unpack_h(ho[k]).float(), rc_unpack_c(co[k])
+        assert torch.isfinite(h2).all() and torch.isfinite(c2).all()
+        eh, ec = (h2 - ref[k][0]).abs().max().item(), (c2 - ref[k][1]).abs().max().item()
+        assert eh < 6e-3 and ec < 2e-4, (k, eh, ec)            # h' is rounded to bf16 (2^-9 relative), c' stays fp32
