@@ -203,8 +203,6 @@ class Workload:
         """One policy + env step with every buffer updated in place (capture-safe)."""
         p = self.ppo
         from hcrl_amd.fused import episode_flags
-        if os.environ.get("FDYN_INPLACE_STATE") == "1":
-            p._state_bufs[1] = p._state_bufs[0]
         nxt = p._state_bufs[1 - p._cur]
         fused_glue = p.policy._fused_ok(p.obs)
         a, _v, _lp, new_states = p.policy.step(p.obs, p.states, p.episode_start, out_states=nxt, keep=p.keep, bump_noise=not fused_glue)

@@ -469,6 +469,16 @@ int launch(const void* x, const void* h_prev, const float* c_prev, const float* 
 extern "C" int fdyn_lstm_cell_mfma64_try(const void* x, int kx, const void* h_prev, int kh, const float* c_prev, const float* keep,
                                          const void* W, const float* bias, void* h_out, float* c_out, int64_t B, int H, void* stream);   // lstm_mfma64.hip
 
+static bool use_mfma64() { static const bool u = [] { const char* e = getenv("FDYN_MFMA64"); return !(e && e[0] == '0'); }(); return u; }
+
+// 1 = fdyn_lstm_cell_mfma may be called with h_out == h_prev and c_out == c_prev for this shape: the one-wave-per-SIMD kernel
+// (lstm_mfma64.hip) gives every wave 64 whole rows -- it loads their h before it stores any h' and reads each c_prev word in
+// the lane that then overwrites it.  The tiled kernel below splits a row's hidden slices over workgroups: never in place.
+extern "C" int fdyn_lstm_cell_mfma_inplace_ok(int kx, int kh, int H, int64_t B)
+{
+    return use_mfma64() && kx == 128 && kh == 256 && H == 256 && B >= 128 * 256 && B % 256 == 0;
+}
+
 extern "C" int fdyn_lstm_cell_mfma(const void* x, int kx, const void* h_prev, int kh, const float* c_prev, const float* keep,
                                    const void* W, const float* bias, void* h_out, float* c_out, float* h_out_f32,
                                    int64_t B, int H, void* stream)
@@ -477,9 +487,12 @@ extern "C" int fdyn_lstm_cell_mfma(const void* x, int kx, const void* h_prev, in
     if (!x || !W || !bias || !h_out) return FDYN_ERR_NULL;
     if (kh > 0 && (!h_prev || !c_prev)) return FDYN_ERR_NULL;
     if (B == 0) return FDYN_OK;
+    // a state updated in place is only safe in the kernel that owns whole rows per wave; anywhere else it would corrupt silently
+    if (kh > 0 && (h_out == h_prev || (c_out && c_out == c_prev)) && !(fdyn_lstm_cell_mfma_inplace_ok(kx, kh, H, B) && !h_out_f32 && c_out))
+        return FDYN_ERR_BAD_SIZE;
     hipStream_t st = (hipStream_t)stream;
     // whole 256-row blocks of the (128, 256) cell, enough of them to give every CU one: the one-wave-per-SIMD kernel
-    static const bool use64 = [] { const char* e = getenv("FDYN_MFMA64"); return !(e && e[0] == '0'); }();
+    const bool use64 = use_mfma64();
     if (use64 && !h_out_f32 && B >= 128 * 256) {
         const int rc = fdyn_lstm_cell_mfma64_try(x, kx, h_prev, kh, c_prev, keep, W, bias, h_out, c_out, B, H, stream);
         if (rc) return rc > 0 ? FDYN_OK : int(hipGetLastError());

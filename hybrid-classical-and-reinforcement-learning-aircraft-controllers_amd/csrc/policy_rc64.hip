@@ -240,7 +240,7 @@ policy_rc64_kernel(const uint8_t* __restrict__ feats /*fragment layout [B/64][2]
                 FENCE();
             });
         });
-        asm volatile("s_nop 15\n\ts_nop 3");            // MFMA result -> VALU read distance (the compiler cannot see into the asm)
+        if constexpr (!(ABL & 64)) asm volatile("s_nop 15\n\ts_nop 3");   // MFMA result -> VALU read distance (the compiler cannot see into the asm)
     };
 
     struct GS { float x[4], y[4], z[4]; };
@@ -279,7 +279,7 @@ policy_rc64_kernel(const uint8_t* __restrict__ feats /*fragment layout [B/64][2]
         if (g == 0) unit(IC<0>{}, IC<0>{}, [&](auto) {}, (u0 + DREQ) % NUNITS, true, 0);
         else unit(IC<0>{}, IC<8 * NS_O>{}, p_o, (u0 + DREQ) % NUNITS, sl == 0, p_cell * 4 * H + 3 * H + 32 * p_sl);
         wait_vm<WAIT_END>();                            // chunk u0 + 1 has landed
-        __syncthreads();
+        if constexpr (!(ABL & 32)) __syncthreads();
 
         // ---- unit 1: gate g -> set 1 ; under it I = 2^(-i log2 e) from set 0
         constexpr int NS_I = 2;
@@ -290,7 +290,7 @@ policy_rc64_kernel(const uint8_t* __restrict__ feats /*fragment layout [B/64][2]
         };
         unit(IC<1>{}, IC<8 * NS_I>{}, p_i, (u0 + 1 + DREQ) % NUNITS, false, sb);
         wait_vm<WAIT_END>();
-        __syncthreads();
+        if constexpr (!(ABL & 32)) __syncthreads();
 
         // ---- unit 2: gate f -> set 0 ; under it i g = sigmoid(i) tanh(g) = (1 - G) / ((1 + G)(1 + I)), G = 2^(-2 g log2 e), from set 1
         constexpr int NS_G = 8;
@@ -307,7 +307,7 @@ policy_rc64_kernel(const uint8_t* __restrict__ feats /*fragment layout [B/64][2]
         };
         unit(IC<2>{}, IC<8 * NS_G>{}, p_g, (u0 + 2 + DREQ) % NUNITS, false, sb + 2 * H);
         wait_vm<WAIT_END_Q2>();
-        __syncthreads();
+        if constexpr (!(ABL & 32)) __syncthreads();
 
         // ---- unit 3: gate o -> set 1 ; under it c' = sigmoid(f) keep c + i g from set 0 -> store, then E = 2^(-2 c' log2 e);
         // each group's c_prev registers are re-requested for the NEXT slice as soon as they have been read
@@ -343,7 +343,7 @@ policy_rc64_kernel(const uint8_t* __restrict__ feats /*fragment layout [B/64][2]
         } else {
             wait_vm<WAIT_END>();
         }
-        __syncthreads();
+        if constexpr (!(ABL & 32)) __syncthreads();
     }
     #undef RC_DECODE
     // ---- drain: the last slice's o epilogue has nothing to hide under

@@ -342,7 +342,8 @@ class RateLSTMPolicy(nn.Module):
                 and w.shape[0] == 4 * H, "lstm_cell_mfma operand shapes"
             # the kernel writes the new state straight into the caller's ping-pong buffers when given (no copies)
             ok = ho is not None and ho.dtype == bf and ho.shape == (B, H) and ho.is_contiguous() and co.dtype == torch.float32 \
-                and co.shape == (B, H) and co.is_contiguous() and (os.environ.get("FDYN_INPLACE_STATE") == "1" or (ho.data_ptr() != hp.data_ptr() and co.data_ptr() != cp.data_ptr()))
+                and co.shape == (B, H) and co.is_contiguous() \
+                and ((ho.data_ptr() != hp.data_ptr() and co.data_ptr() != cp.data_ptr()) or lib.fdyn_lstm_cell_mfma_inplace_ok(128, H, H, B))
             h = ho if ok else torch.empty((B, H), dtype=bf, device=dev)
             c = co if ok else torch.empty((B, H), dtype=torch.float32, device=dev)
             _lib.check(lib.fdyn_lstm_cell_mfma(feats.data_ptr(), feats.shape[1], hp.data_ptr(), H, cp.data_ptr(),
@@ -362,6 +363,15 @@ class RateLSTMPolicy(nn.Module):
                                               lat_vf.data_ptr(), B, st), "policy_trunks")
             return lat_pi, lat_vf, RNNStates(*out)
         return self._mlp_bf16(out[0], inf["pi"]), self._mlp_bf16(out[2], inf["vf"]), RNNStates(*out)
+
+    def recurrent_inplace_ok(self, batch: int, device) -> bool:
+        """True if the fused rollout path may update the recurrent state of `batch` envs IN PLACE (one state set instead of a
+        ping-pong pair: the footprint that decides whether the state survives in the Infinity Cache between steps)."""
+        from . import _lib
+        if not (self.use_lstm and self.compute_dtype == torch.bfloat16 and torch.device(device).type == "cuda" and self.hidden == 256
+                and os.environ.get("FDYN_INPLACE_STATE", "1") != "0" and not os.environ.get("FDYN_NO_MFMA")):
+            return False
+        return bool(_lib.load().fdyn_lstm_cell_mfma_inplace_ok(128, self.hidden, self.hidden, int(batch)))
 
     def noise_counter(self, device):
         """The device-side step counter of the fused path's action noise (created on first use)."""

@@ -188,7 +188,10 @@ class RecurrentPPO:
         hd = pol.compute_dtype if (pol.compute_dtype is not None and self.device.type == "cuda") else torch.float32
         z = lambda dt: torch.zeros(n, pol.hidden, dtype=dt, device=self.device)  # noqa: E731
         mk = lambda: RNNStates(z(hd), z(torch.float32), z(hd), z(torch.float32))  # noqa: E731
-        self._state_bufs, self._cur = [mk(), mk()], 0        # ping-pong: step t reads one set and writes the other
+        # ping-pong: step t reads one set and writes the other -- or, where the cell kernel owns whole rows per wave, ONE set
+        # updated in place (both entries are the same buffers)
+        first = mk()
+        self._state_bufs, self._cur = [first, first if pol.recurrent_inplace_ok(n, self.device) else mk()], 0
         self.rollout_states = mk()
 
     @property

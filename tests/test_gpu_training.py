@@ -805,3 +805,32 @@ def test_recurrent_cells_one_launch_matches_plain_torch_fp32(B, inplace):
         assert torch.isfinite(h2).all() and torch.isfinite(c2).all()
         eh, ec = (h2 - ref[k][0]).abs().max().item(), (c2 - ref[k][1]).abs().max().item()
         assert eh < 6e-3 and ec < 2e-4, (k, eh, ec)            # h' is rounded to bf16 (2^-9 relative), c' stays fp32
+
+
+def test_recurrent_state_in_place_equals_ping_pong():
+    """One recurrent-state set updated IN PLACE (what RecurrentPPO uses at batches the one-wave-per-SIMD cell kernel serves)
+    gives bit for bit what the ping-pong pair gives; shapes whose kernel splits a row over workgroups refuse aliased state."""
+    from hcrl_amd import _lib
+    from hcrl_amd.policy import RNNStates
+    torch.manual_seed(1)
+    p = RateLSTMPolicy(compute_dtype=torch.bfloat16).cuda()
+    p.prepare_inference()
+    B = 65536
+    assert p.recurrent_inplace_ok(B, "cuda") and not p.recurrent_inplace_ok(4096, "cuda")
+    obs = torch.randn(B, 18, device="cuda")
+    mk = lambda: RNNStates(*(torch.randn(B, 256, device="cuda").to(dt) * 0.5 for dt in (torch.bfloat16, torch.float32) * 2))  # noqa: E731
+    st = mk()
+    st2 = RNNStates(*(t.clone() for t in st))
+    out = RNNStates(*(torch.empty_like(t) for t in st))
+    start = (torch.rand(B, device="cuda") < 0.02).float()
+    with torch.no_grad():
+        a1, v1, _, s1 = p.step(obs, st, start, deterministic=True, out_states=out)
+        a2, v2, _, s2 = p.step(obs, st2, start, deterministic=True, out_states=st2)
+    assert all(a.data_ptr() == b.data_ptr() for a, b in zip(s2, st2))          # really in place
+    assert all(torch.equal(a, b) for a, b in zip(s1, s2)) and torch.equal(a1, a2) and torch.equal(v1, v2)
+    lib, n = _lib.load(), 512
+    x, h, c = torch.zeros(n, 128, device="cuda", dtype=torch.bfloat16), torch.zeros(n, 256, device="cuda", dtype=torch.bfloat16), torch.zeros(n, 256, device="cuda")
+    w, b = torch.zeros(1024, 384, device="cuda", dtype=torch.bfloat16), torch.zeros(1024, device="cuda")
+    rc = lib.fdyn_lstm_cell_mfma(x.data_ptr(), 128, h.data_ptr(), 256, c.data_ptr(), None, w.data_ptr(), b.data_ptr(), h.data_ptr(),
+                                 c.data_ptr(), None, n, 256, _lib.current_stream())
+    assert rc == _lib.FDYN_ERR_BAD_SIZE
