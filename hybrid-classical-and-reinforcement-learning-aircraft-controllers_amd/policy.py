@@ -90,7 +90,7 @@ def pack_fe_weights(w_emb, w1, w2, w_proj):
     H = w1.shape[0] // 4
 
     def perm(K):
-        return torch.tensor([16 * (k // 16) + _KPERM16[k % 16] for k in range(K)], device=w1.device)
+        return _kperm(K, w1.device)
 
     def chunk(rows):                      # rows [R, K] -> bytes of the padded LDS image, a whole number of 1 KB pieces
         R = rows.shape[0]
@@ -113,8 +113,16 @@ def pack_fe_weights(w_emb, w1, w2, w_proj):
 # ---- csrc/policy_rc64.hip: both recurrent cells in one launch, lane = batch row ---------------------------------------------
 # The kernel keeps activations and state in its own layouts (whole 1 KB wave accesses, a lane touches only its own row).  Row
 # 64 wb + 32 t + r lives in lane r + 32 hf of wave-block wb, tile t; hidden unit n = 32 sl + 16 hq + 8 p2 + 4 hf + p01.
+_KPERM_CACHE = {}
+
+
 def _kperm(K, device):
-    return torch.tensor([16 * (k // 16) + _KPERM16[k % 16] for k in range(K)], device=device)
+    """Column order of a K-wide weight matrix whose input arrives as MFMA output fragments; one device tensor per (K, device),
+    built once (prepare_inference runs before every rollout: a torch.tensor(list, device=cuda) there is a synchronous H2D copy)."""
+    key = (int(K), str(device))
+    if key not in _KPERM_CACHE:
+        _KPERM_CACHE[key] = torch.tensor([16 * (k // 16) + _KPERM16[k % 16] for k in range(K)], device=device)
+    return _KPERM_CACHE[key]
 
 
 def rc_pack_x(x):
@@ -277,7 +285,7 @@ class RateLSTMPolicy(nn.Module):
         # the two trunks as one kernel (csrc/policy_trunk.hip) when they have the reference's shape [256 -> 128 -> 64]
         pi_l, vf_l = [m for m in self.pi_net if isinstance(m, nn.Linear)], [m for m in self.vf_net if isinstance(m, nn.Linear)]
         if (len(pi_l) == 2 and len(vf_l) == 2 and all(l[0].weight.shape == (128, 256) and l[1].weight.shape == (64, 128) for l in (pi_l, vf_l))):
-            perm = torch.tensor([16 * (k // 16) + _KPERM16[k % 16] for k in range(128)], device=pi_l[0].weight.device)
+            perm = _kperm(128, pi_l[0].weight.device)
             new["trunk_w1"] = torch.stack([pi_l[0].weight.detach(), vf_l[0].weight.detach()]).to(bf).contiguous()
             new["trunk_b1"] = torch.stack([pi_l[0].bias.detach(), vf_l[0].bias.detach()]).float().contiguous()
             new["trunk_w2p"] = torch.stack([pi_l[1].weight.detach()[:, perm], vf_l[1].weight.detach()[:, perm]]).to(bf).contiguous()

@@ -35,3 +35,29 @@ for name, fn in ((tag, rc),) + ((("lstm_mfma64 x 2, out of place", old),) if rcl
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 50 * 1e3
     print(f"{name:50s} {us:8.1f} us   {2 * 2 * B * 384 * 1024 / us / 1e6:8.1f} TFLOP/s   {2 * 218.1 / us * 1e3 / 1e3:6.2f} TB/s of state + activation traffic")
+
+if hasattr(rclib, "fdyn_rc64_read_stamps"):
+    import numpy as np
+    buf = np.zeros(256 * 64 * 4, np.uint64)
+    rc(); torch.cuda.synchronize()
+    rclib.fdyn_rc64_read_stamps(buf.ctypes.data_as(ctypes.c_void_p))
+    st = buf.reshape(256, 64, 4).astype(np.int64)
+    mf, wt, br = st[:, :, 1] - st[:, :, 0], st[:, :, 2] - st[:, :, 1], st[:, :, 3] - st[:, :, 2]
+    gap = st[:, 1:, 0] - st[:, :-1, 3]
+    print("shader cycles per unit (median over 256 workgroups; wave 0): unit body | end wait (vmcnt) | barrier | to next unit")
+    for q, name in enumerate(("i + P_O", "g + P_I", "f + P_G", "o + P_F")):
+        sel = np.arange(q, 64, 4)[1:]
+        print(f"  {name:8s} {np.median(mf[:, sel]):7.0f} | {np.median(wt[:, sel]):6.0f} | {np.median(br[:, sel]):6.0f} | {np.median(gap[:, sel[:-1]]):5.0f}    (p90 body {np.percentile(mf[:, sel], 90):.0f}, wait {np.percentile(wt[:, sel], 90):.0f}, barrier {np.percentile(br[:, sel], 90):.0f})")
+    tot = st[:, -1, 3] - st[:, 0, 0]
+    print(f"  whole loop: median {np.median(tot):.0f} cycles, sum of bodies {np.median(mf.sum(1)):.0f}, waits {np.median(wt.sum(1)):.0f}, barriers {np.median(br.sum(1)):.0f}")
+
+if hasattr(rclib, "fdyn_rc64_read_gap_stamps"):
+    import numpy as np
+    buf = np.zeros(256 * 98, np.uint64)
+    rc(); torch.cuda.synchronize()
+    rclib.fdyn_rc64_read_gap_stamps(buf.ctypes.data_as(ctypes.c_void_p))
+    st = buf.reshape(256, 2, 49).astype(np.int64)
+    d = np.median(st[:, :, 1:] - st[:, :, :-1], axis=0)
+    for w, name in enumerate(("unit i + P_O", "unit o + P_F")):
+        print(name, "cycles per MFMA gap (median over workgroups), gaps 0..47:")
+        print("   " + " ".join(f"{int(x):4d}" for x in d[w][:24])); print("   " + " ".join(f"{int(x):4d}" for x in d[w][24:]))
