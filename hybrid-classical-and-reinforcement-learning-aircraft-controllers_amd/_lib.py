@@ -43,6 +43,7 @@ SIGNATURES = {
     "fdyn_colsum_partials": (_i, [_p, _i64, _i, _p, _p, _p]),
     "fdyn_episode_flags": (_i, [_p, _p, _p, _p, _p, _i64, _p]),
     "fdyn_policy_trunks": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
+    "fdyn_policy_trunks_heads": (_i, [_p] * 11 + [_u64, _p, _i, _p, _p, _p, _i64, _p]),
     "fdyn_agent_step_f64": (_i, [_i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _i64, _d, _i, _p, _p]),
     "fdyn_agent_step_mixed": (_i, [_i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _i64, _d, _i, _p, _p]),
     "fdyn_agent_step_f32": (_i, [_i, _p, _p, _p, _p, _i, _p, _i, _p, _p, _i64, _d, _i, _p, _p]),

@@ -11,6 +11,7 @@
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 #include "../../include/fdyn.h"
+#include "philox.hpp"
 
 namespace {
 
@@ -347,18 +348,6 @@ gae_kernel(const float* __restrict__ rew, const float* __restrict__ val, const f
 // 16-byte load and store; the normals come from Philox-4x32-10 keyed by (seed, env, *step) (Box-Muller), where the step counter
 // is a word in DEVICE memory that the caller bumps on the stream -- so a captured graph draws fresh noise on every replay.
 // Replaces a dozen tiny element-wise / reduction launches per policy step.
-__device__ __forceinline__ void philox4(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t (&o)[4])
-{
-    uint32_t k0 = uint32_t(seed), k1 = uint32_t(seed >> 32);
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-        const uint64_t p0 = uint64_t(0xD2511F53u) * c0, p1 = uint64_t(0xCD9E8D57u) * c2;
-        const uint32_t n0 = uint32_t(p1 >> 32) ^ c1 ^ k0, n2 = uint32_t(p0 >> 32) ^ c3 ^ k1;
-        c1 = uint32_t(p1); c3 = uint32_t(p0); c0 = n0; c2 = n2;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
-}
 template <typename MT>
 __global__ void __launch_bounds__(256)
 gaussian_head_kernel(const MT* __restrict__ mean /*[B][4]*/, const float* __restrict__ log_std /*[4]*/, uint64_t seed,

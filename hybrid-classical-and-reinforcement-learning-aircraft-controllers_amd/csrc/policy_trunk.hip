@@ -20,6 +20,7 @@
 #include <stdint.h>
 #include <type_traits>
 #include "../../include/fdyn.h"
+#include "philox.hpp"
 
 namespace {
 
@@ -40,13 +41,24 @@ template <int I, int N, class F> __device__ __forceinline__ void sfor(F&& f)
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor<I + 1, N>(f); }
 }
 
+// output heads fused behind the trunks (HEADS): what fdyn_policy_heads does in a second launch -- mean = lat_pi Wa^T + ba,
+// value = lat_vf wv + bv, Gaussian sampling + log-probability -- on the bf16-rounded trunk outputs while they are still in
+// registers: a lane holds 32 of its row's 64 features, its partner lane (b, 1 - hf) the other 32.
+struct HeadArgs {
+    const uint16_t* Wa; const uint16_t* ba; const uint16_t* wv; const uint16_t* bv;      // [4][64], [4], [64], [1] bf16
+    const float* log_std; uint64_t seed; const uint32_t* step; int deterministic;
+    float* actions; float* logp; float* value;                                         // [B][4], [B], [B]
+};
+
+template <bool HEADS>
 __global__ void __launch_bounds__(256, 1)
 policy_trunk_kernel(const uint16_t* __restrict__ h_pi, const uint16_t* __restrict__ h_vf /*[B][256] bf16*/,
                     const uint16_t* __restrict__ W1 /*[2][128][256] bf16*/, const float* __restrict__ b1 /*[2][128]*/,
                     const uint16_t* __restrict__ W2p /*[2][64][128] bf16, k permuted per block of 16*/,
                     const float* __restrict__ b2 /*[2][64]*/, uint16_t* __restrict__ lat_pi, uint16_t* __restrict__ lat_vf /*[B][64] bf16*/,
-                    int64_t B, int64_t rows_per_wg)
+                    int64_t B, int64_t rows_per_wg, HeadArgs hd)
 {
+    __shared__ float s_hw[HEADS ? 4 * N2 + 4 : 1];     // this trunk's head: pi [4][64] + ba[4] ; vf [64] + bv
     __shared__ __attribute__((aligned(16))) uint16_t s_w1[N1 * ROW1];
     __shared__ __attribute__((aligned(16))) uint16_t s_w2[N2 * ROW2];
     __shared__ __attribute__((aligned(16))) float s_b1[N1];
@@ -89,6 +101,11 @@ policy_trunk_kernel(const uint16_t* __restrict__ h_pi, const uint16_t* __restric
             const int v = tid + 256 * i, row = v / (N1 / 8), c = v % (N1 / 8);
             *reinterpret_cast<u32x4_t*>(s_w2 + row * ROW2 + c * 8) = w2r[i];
         }
+    }
+    if constexpr (HEADS) {
+        auto bf = [](uint16_t b) { return __uint_as_float(uint32_t(b) << 16); };
+        if (trunk == 0) { s_hw[tid] = bf(hd.Wa[tid]); if (tid < 4) s_hw[4 * N2 + tid] = bf(hd.ba[tid]); }
+        else if (tid < N2 + 1) s_hw[tid] = tid < N2 ? bf(hd.wv[tid]) : bf(hd.bv[0]);
     }
     if (tid < N1) s_b1[tid] = b1[trunk * N1 + tid];
     if (tid < N2) s_b2[tid] = b2[trunk * N2 + tid];
@@ -195,6 +212,7 @@ policy_trunk_kernel(const uint16_t* __restrict__ h_pi, const uint16_t* __restric
             for (int t = 0; t < N2 / 32; ++t)
                 acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, cn[s & 1][t]), b2f[s], acc2[t], 0, 0, 0);
         }
+        float hm[4] = { 0.0f, 0.0f, 0.0f, 0.0f };         // HEADS: this lane's share of the head dot products
 #pragma unroll
         for (int t = 0; t < N2 / 32; ++t) {
 #pragma unroll
@@ -207,7 +225,50 @@ policy_trunk_kernel(const uint16_t* __restrict__ h_pi, const uint16_t* __restric
                     const float v = acc2[t][4 * j + i] + bv[i];
                     o[i] = static_cast<__bf16>(v > 0.0f ? v : 0.0f);
                 }
-                if (my_row < B) *reinterpret_cast<uint2*>(lat + my_row * N2 + 32 * t + 8 * j + 4 * hf) = __builtin_bit_cast(uint2, o);
+                if constexpr (HEADS) {
+                    const int f0 = 32 * t + 8 * j + 4 * hf;                            // features f0 .. f0 + 3 of this lane's row
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float v = static_cast<float>(o[i]);                      // the value fdyn_policy_heads would read back
+                        if (trunk == 0) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) hm[k] = __builtin_fmaf(v, s_hw[k * N2 + f0 + i], hm[k]);
+                        } else {
+                            hm[0] = __builtin_fmaf(v, s_hw[f0 + i], hm[0]);
+                        }
+                    }
+                } else {
+                    if (my_row < B) *reinterpret_cast<uint2*>(lat + my_row * N2 + 32 * t + 8 * j + 4 * hf) = __builtin_bit_cast(uint2, o);
+                }
+            }
+        }
+        if constexpr (HEADS) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) hm[k] += __shfl_xor(hm[k], 32);               // the partner lane's 32 features
+            if (hf == 0 && my_row < B) {
+                if (trunk == 1) {
+                    hd.value[my_row] = hm[0] + s_hw[N2];
+                } else {
+                    float z[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+                    if (!hd.deterministic) {                                           // as policy_heads_kernel: same key, same Box-Muller
+                        uint32_t rn[4];
+                        philox4(hd.seed, uint32_t(my_row), uint32_t(my_row >> 32), hd.step ? *hd.step : 0u, 0x51u, rn);
+                        const float u0 = (float(rn[0] >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = (float(rn[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+                        const float u2 = (float(rn[2] >> 8) + 0.5f) * (1.0f / 16777216.0f), u3 = (float(rn[3] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+                        const float ra = sqrtf(-2.0f * __logf(u0)), rb = sqrtf(-2.0f * __logf(u2));
+                        z[0] = ra * __cosf(6.283185307f * u1); z[1] = ra * __sinf(6.283185307f * u1);
+                        z[2] = rb * __cosf(6.283185307f * u3); z[3] = rb * __sinf(6.283185307f * u3);
+                    }
+                    float a[4], lp = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float ls = hd.log_std[k];
+                        a[k] = hm[k] + s_hw[4 * N2 + k] + __expf(ls) * z[k];
+                        lp += -0.5f * z[k] * z[k] - ls - 0.9189385332046727f;
+                    }
+                    reinterpret_cast<float4*>(hd.actions)[my_row] = make_float4(a[0], a[1], a[2], a[3]);
+                    hd.logp[my_row] = lp;
+                }
             }
         }
     }
@@ -224,8 +285,27 @@ extern "C" int fdyn_policy_trunks(const void* h_pi, const void* h_vf, const void
     const int64_t blocks128 = (B + 127) / 128;
     const int64_t gx = blocks128 < TRUNK_WGS ? blocks128 : TRUNK_WGS;
     const int64_t rows_per_wg = ((blocks128 + gx - 1) / gx) * 128;
-    hipLaunchKernelGGL(policy_trunk_kernel, dim3(unsigned(gx), 2), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)h_pi,
+    hipLaunchKernelGGL(policy_trunk_kernel<false>, dim3(unsigned(gx), 2), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)h_pi,
                        (const uint16_t*)h_vf, (const uint16_t*)W1, b1, (const uint16_t*)W2p, b2, (uint16_t*)lat_pi, (uint16_t*)lat_vf, B,
-                       rows_per_wg);
+                       rows_per_wg, HeadArgs{});
+    return int(hipGetLastError());
+}
+
+extern "C" int fdyn_policy_trunks_heads(const void* h_pi, const void* h_vf, const void* W1, const float* b1, const void* W2p, const float* b2,
+                                        const void* Wa, const void* ba, const void* wv, const void* bv, const float* log_std, uint64_t seed,
+                                        const uint32_t* step, int deterministic, float* actions, float* logp, float* value, int64_t B,
+                                        void* stream)
+{
+    if (B < 0) return FDYN_ERR_BAD_SIZE;
+    if (!h_pi || !h_vf || !W1 || !b1 || !W2p || !b2 || !Wa || !ba || !wv || !bv || !log_std || !actions || !logp || !value) return FDYN_ERR_NULL;
+    if (B == 0) return FDYN_OK;
+    const int64_t blocks128 = (B + 127) / 128;
+    const int64_t gx = blocks128 < TRUNK_WGS ? blocks128 : TRUNK_WGS;
+    const int64_t rows_per_wg = ((blocks128 + gx - 1) / gx) * 128;
+    const HeadArgs hd = { (const uint16_t*)Wa, (const uint16_t*)ba, (const uint16_t*)wv, (const uint16_t*)bv, log_std, seed, step, deterministic,
+                          actions, logp, value };
+    hipLaunchKernelGGL(policy_trunk_kernel<true>, dim3(unsigned(gx), 2), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)h_pi,
+                       (const uint16_t*)h_vf, (const uint16_t*)W1, b1, (const uint16_t*)W2p, b2, (uint16_t*)nullptr, (uint16_t*)nullptr, B,
+                       rows_per_wg, hd);
     return int(hipGetLastError());
 }

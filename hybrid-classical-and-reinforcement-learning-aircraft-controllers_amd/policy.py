@@ -315,8 +315,10 @@ class RateLSTMPolicy(nn.Module):
         return (inf is not None and obs.is_cuda and self.compute_dtype == torch.bfloat16 and not torch.is_grad_enabled()
                 and self.hidden == 256 and all(w.shape[1] in (128, 256) for w in inf["fe_w"]))
 
-    def _core_fused(self, obs, states: RNNStates, keep, out_states: Optional[RNNStates] = None):
-        """Explicit bf16 inference path (no autocast): pre-cast Linear weights + one MFMA kernel per LSTM cell."""
+    def _core_fused(self, obs, states: RNNStates, keep, out_states: Optional[RNNStates] = None, heads: Optional[dict] = None):
+        """Explicit bf16 inference path (no autocast): pre-cast Linear weights + one MFMA kernel per LSTM cell.
+        heads = {"deterministic": bool}: where the trunk kernel serves the shape, the output heads and the sampling run behind
+        the trunks in the same launch and the return value is (actions, value, logp, new_states)."""
         from . import _lib
         lib, inf, B, H = _lib.load(), self._inf, obs.shape[0], self.hidden
         bf, dev = torch.bfloat16, obs.device
@@ -364,6 +366,18 @@ class RateLSTMPolicy(nn.Module):
             assert h_pi.dtype == bf and h_vf.dtype == bf and h_pi.is_contiguous() and h_vf.is_contiguous() \
                 and h_pi.shape == (B, 256) and h_vf.shape == (B, 256) and inf["trunk_w1"].shape == (2, 128, 256) \
                 and inf["trunk_w2p"].shape == (2, 64, 128), "policy_trunks operand shapes"
+            if heads is not None and inf["act"][0].shape == (ACT_DIM, 64) and inf["val"][0].shape == (1, 64) \
+                    and not os.environ.get("FDYN_NO_TRUNK_HEADS"):
+                actions = torch.empty((B, ACT_DIM), dtype=torch.float32, device=dev)
+                logp = torch.empty(B, dtype=torch.float32, device=dev)
+                value = torch.empty(B, dtype=torch.float32, device=dev)
+                _lib.check(lib.fdyn_policy_trunks_heads(
+                    h_pi.data_ptr(), h_vf.data_ptr(), inf["trunk_w1"].data_ptr(), inf["trunk_b1"].data_ptr(), inf["trunk_w2p"].data_ptr(),
+                    inf["trunk_b2"].data_ptr(), inf["act"][0].data_ptr(), inf["act"][1].data_ptr(), inf["val"][0].data_ptr(),
+                    inf["val"][1].data_ptr(), self.log_std.detach().float().contiguous().data_ptr(), self._noise_seed,
+                    self._noise_step.data_ptr(), int(heads["deterministic"]), actions.data_ptr(), logp.data_ptr(), value.data_ptr(), B, st),
+                    "policy_trunks_heads")
+                return actions, value, logp, RNNStates(*out)
             lat_pi = torch.empty((B, 64), dtype=bf, device=dev)
             lat_vf = torch.empty((B, 64), dtype=bf, device=dev)
             _lib.check(lib.fdyn_policy_trunks(h_pi.data_ptr(), h_vf.data_ptr(), inf["trunk_w1"].data_ptr(), inf["trunk_b1"].data_ptr(),
@@ -396,9 +410,16 @@ class RateLSTMPolicy(nn.Module):
         if self._fused_ok(obs):
             if keep is None:
                 keep = (1.0 - episode_start.float()).contiguous()        # the mask is applied inside the kernel
-            lat_pi, lat_vf, new_states = self._core_fused(obs, states, keep, out_states)
-            # output heads + sampling + log-prob in ONE launch (in-kernel Philox keyed by a per-policy seed, the env index
-            # and a step counter that lives on the device so a captured graph draws fresh noise on every replay)
+            # output heads + sampling + log-prob ride behind the trunks (or in ONE launch of their own): in-kernel Philox keyed
+            # by a per-policy seed, the env index and a step counter that lives on the device, so a captured graph draws fresh
+            # noise on every replay
+            self.noise_counter(obs.device)
+            if bump_noise:
+                self._noise_step.add_(1)
+            res = self._core_fused(obs, states, keep, out_states, heads={"deterministic": deterministic})
+            if len(res) == 4:
+                return res
+            lat_pi, lat_vf, new_states = res
             from . import _lib
             inf, B, dev = self._inf, obs.shape[0], obs.device
             assert lat_pi.shape == (B, 64) and lat_vf.shape == (B, 64) and lat_pi.is_contiguous() and lat_vf.is_contiguous() \
@@ -406,9 +427,6 @@ class RateLSTMPolicy(nn.Module):
             actions = torch.empty((B, ACT_DIM), dtype=torch.float32, device=dev)
             logp = torch.empty(B, dtype=torch.float32, device=dev)
             value = torch.empty(B, dtype=torch.float32, device=dev)
-            self.noise_counter(dev)
-            if bump_noise:
-                self._noise_step.add_(1)
             _lib.check(_lib.load().fdyn_policy_heads(lat_pi.data_ptr(), lat_vf.data_ptr(), inf["act"][0].data_ptr(),
                                                      inf["act"][1].data_ptr(), inf["val"][0].data_ptr(), inf["val"][1].data_ptr(),
                                                      self.log_std.detach().float().contiguous().data_ptr(), self._noise_seed,

@@ -213,6 +213,13 @@ int fdyn_lstm_cell0_bwd(const void* act, int bf16, const void* dh, void* dgates,
  * first layer's output tile is the second layer's MFMA operand as it stands -- and b2 [2][64] fp32. */
 int fdyn_policy_trunks(const void* h_pi, const void* h_vf, const void* W1, const float* b1, const void* W2p, const float* b2,
                        void* lat_pi, void* lat_vf, int64_t B, void* stream);
+/* The same two trunks with the output heads and the sampling behind them in ONE launch (what fdyn_policy_trunks +
+ * fdyn_policy_heads do in two, with lat_pi / lat_vf never leaving the registers): Wa [4][64], ba [4], wv [64], bv [1] bf16,
+ * log_std [4] fp32, Philox key (seed, row, *step) as fdyn_policy_heads -> actions [B][4], logp [B], value [B] fp32.        */
+int fdyn_policy_trunks_heads(const void* h_pi, const void* h_vf, const void* W1, const float* b1, const void* W2p, const float* b2,
+                             const void* Wa, const void* ba, const void* wv, const void* bv, const float* log_std, uint64_t seed,
+                             const uint32_t* step, int deterministic, float* actions, float* logp, float* value, int64_t B,
+                             void* stream);
 /* Rollout glue in one launch: episode_start [n] = (terminated | truncated) as fp32, keep [n] = 1 - episode_start (either may be
  * NULL), *counter += 1 (NULL = none: the device-side step counter of fdyn_policy_heads / fdyn_gaussian_head's action noise). */
 int fdyn_episode_flags(const uint8_t* terminated, const uint8_t* truncated, float* episode_start, float* keep, int32_t* counter,

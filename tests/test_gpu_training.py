@@ -834,3 +834,29 @@ def test_recurrent_state_in_place_equals_ping_pong():
     rc = lib.fdyn_lstm_cell_mfma(x.data_ptr(), 128, h.data_ptr(), 256, c.data_ptr(), None, w.data_ptr(), b.data_ptr(), h.data_ptr(),
                                  c.data_ptr(), None, n, 256, _lib.current_stream())
     assert rc == _lib.FDYN_ERR_BAD_SIZE
+
+
+@pytest.mark.parametrize("B", [300, 65536])
+def test_heads_behind_the_trunks_equal_the_two_launch_path(B, monkeypatch):
+    """fdyn_policy_trunks_heads (trunks -> output heads -> Gaussian sampling in one launch, lat never leaves the registers)
+    against fdyn_policy_trunks + fdyn_policy_heads: same Philox key, same bf16 rounding of the trunk outputs; only the order of
+    the 64-term head sums differs (fp32)."""
+    torch.manual_seed(3)
+    p = RateLSTMPolicy(compute_dtype=torch.bfloat16).cuda()
+    with torch.no_grad():
+        p.action_net.weight.mul_(30.0)                      # the 0.01-gain initialisation would leave the means ~0: make them visible
+        p.log_std.fill_(-0.7)
+    p.prepare_inference()
+    obs = torch.randn(B, 18, device="cuda")
+    st = p.initial_state(B, "cuda")
+    st = type(st)(*((t + 0.3 * torch.randn_like(t)).to(dt) for t, dt in zip(st, (torch.bfloat16, torch.float32) * 2)))
+    start = (torch.rand(B, device="cuda") < 0.1).float()
+    with torch.no_grad():
+        a1, v1, lp1, _ = p.step(obs, st, start, bump_noise=False)
+        monkeypatch.setenv("FDYN_NO_TRUNK_HEADS", "1")
+        a0, v0, lp0, _ = p.step(obs, st, start, bump_noise=False)
+        monkeypatch.delenv("FDYN_NO_TRUNK_HEADS")
+        ad, vd, _, _ = p.step(obs, st, start, deterministic=True, bump_noise=False)
+    assert (a1 - a0).abs().max() < 2e-5 and (v1 - v0).abs().max() < 2e-5 and torch.equal(lp1, lp0)
+    assert (a1 - ad).abs().max() > 0.1 and (a1.std(0) > 0.3).all()          # really sampled, really different per row
+    assert torch.equal(vd, v1)
