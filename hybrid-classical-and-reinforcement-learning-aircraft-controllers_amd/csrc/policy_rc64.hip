@@ -55,10 +55,20 @@ constexpr int DREQ = NBUF - 1;                      // (a fifth buffer, or fragm
 constexpr int WPF = 1;                              //  profiles/r03_rc64_ablations.log) k-steps a weight fragment is read ahead of its MFMAs
 constexpr int NPWE = CHUNK_PIECES / 4;                  // vector-memory operations a wave issues per unit: DMA pieces ...
 constexpr int ST_Q3 = 8 + 8;                            // ... c_prev loads + c' stores under the o unit (h' stores under i: 0 or 4)
-// at the end of a unit the next chunk (requested DREQ - 1 units earlier) must have landed: everything a wave has issued since
-// then may stay in flight -- counted with the h' stores left out (a smaller count waits for more, never for less)
-constexpr int WAIT_END = (DREQ - 1) * NPWE + ST_Q3 > 63 ? 63 : (DREQ - 1) * NPWE + ST_Q3;
-constexpr int WAIT_END_Q2 = DREQ == 3 ? (DREQ - 1) * NPWE : WAIT_END;      // three-deep ring: the o unit's words are older than the i chunk's request
+#ifndef RC64_PIECE_EVERY
+#define RC64_PIECE_EVERY 6
+#endif
+// A wave's DMA pieces are dealt out over the unit, one per PIECE_EVERY MFMAs: vector-memory instructions issued back to back
+// hold the wave for 300-400 cycles apiece once the CU's memory queue is full (profiles/r03_rc64_gap_stamps.log; the same
+// finding as lstm_mfma64.hip's DMA_EVERY).
+constexpr int PIECE_EVERY = RC64_PIECE_EVERY;
+static_assert((NPWE - 1) * PIECE_EVERY < 2 * KSTEPS, "the request must fit into the unit");
+// at the end of unit u chunk u + 1 (requested during unit u - 2) must have landed: what a wave has certainly issued after that
+// chunk's last piece may stay in flight -- the pieces of units u - 1 and u and their state words, the h' stores left out (a
+// smaller count waits for more, never for less)
+constexpr int WAIT_END_Q03 = (DREQ - 1) * NPWE + ST_Q3;     // i unit: the previous o unit's words ; o unit: its own
+constexpr int WAIT_END_Q12 = (DREQ - 1) * NPWE;             // g and f units: no state words in them or before them
+static_assert(DREQ == 3, "the wait counts above are written for a four-deep ring");
 constexpr int AX = 0, AH = 64, ACP = 192;           // accumulator-register regions (inline assembly only)
 constexpr float L2E = 1.4426950408889634f;
 
@@ -223,7 +233,7 @@ policy_rc64_kernel(const uint8_t* __restrict__ feats /*fragment layout [B/64][2]
                 if constexpr (t == 0 && ks + WPF < KSTEPS) w[(ks + WPF) % (WPF + 1)] = wfrag(buf, ks + WPF);
                 if constexpr (ks == 0) mfma_a0<slab_reg(t, ks)>(acc[Q & 1][t], w[ks % (WPF + 1)]);
                 else mfma_a<slab_reg(t, ks)>(acc[Q & 1][t], w[ks % (WPF + 1)]);
-                if constexpr (m < NPWE) req_piece(m, next_chunk);
+                if constexpr (m % PIECE_EVERY == 0 && m / PIECE_EVERY < NPWE) req_piece(m / PIECE_EVERY, next_chunk);
                 if constexpr (m >= 1) sfor<((m - 1) * U) / (M - 1), (m * U) / (M - 1)>([&](auto UU) { micro(UU); });
                 FENCE();
             });
@@ -266,7 +276,7 @@ policy_rc64_kernel(const uint8_t* __restrict__ feats /*fragment layout [B/64][2]
         };
         if (g == 0) unit(IC<0>{}, IC<0>{}, [&](auto) {}, (u0 + DREQ) % NUNITS, true, 0);
         else unit(IC<0>{}, IC<8 * NS_O>{}, p_o, (u0 + DREQ) % NUNITS, sl == 0, p_cell * 4 * H + 3 * H + 32 * p_sl);
-        wait_vm<WAIT_END>();                            // chunk u0 + 1 has landed
+        wait_vm<WAIT_END_Q03>();                        // chunk u0 + 1 has landed
         __syncthreads();
 
         // ---- unit 1: gate g -> set 1 ; under it I = 2^(-i log2 e) from set 0
@@ -277,7 +287,7 @@ policy_rc64_kernel(const uint8_t* __restrict__ feats /*fragment layout [B/64][2]
             } else { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; V[t][4 * q + i] = ex2(s.x[i]); }); }
         };
         unit(IC<1>{}, IC<8 * NS_I>{}, p_i, (u0 + 1 + DREQ) % NUNITS, false, sb);
-        wait_vm<WAIT_END>();
+        wait_vm<WAIT_END_Q12>();
         __syncthreads();
 
         // ---- unit 2: gate f -> set 0 ; under it i g = sigmoid(i) tanh(g) = (1 - G) / ((1 + G)(1 + I)), G = 2^(-2 g log2 e), from set 1
@@ -294,7 +304,7 @@ policy_rc64_kernel(const uint8_t* __restrict__ feats /*fragment layout [B/64][2]
             } else { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; V[t][4 * q + i] = s.y[i] * s.z[i]; }); }
         };
         unit(IC<2>{}, IC<8 * NS_G>{}, p_g, (u0 + 2 + DREQ) % NUNITS, false, sb + 2 * H);
-        wait_vm<WAIT_END_Q2>();
+        wait_vm<WAIT_END_Q12>();
         __syncthreads();
 
         // ---- unit 3: gate o -> set 1 ; under it c' = sigmoid(f) keep c + i g from set 0 -> store, then E = 2^(-2 c' log2 e);
@@ -327,9 +337,9 @@ policy_rc64_kernel(const uint8_t* __restrict__ feats /*fragment layout [B/64][2]
         p_sl = sl; p_cell = cell; p_hlane = cp.h_out + (wb * (2 * HSTEPS) + 2 * sl) * 1024 + lane16;
         if (g == NSLICE - 1) {                          // the actor is done with its h fragments: the critic's may come in
             load_h(critic.h_in);
-            wait_vm<(WAIT_END + 2 * HSTEPS > 63 ? 63 : WAIT_END + 2 * HSTEPS)>();
+            wait_vm<(WAIT_END_Q03 + 2 * HSTEPS > 63 ? 63 : WAIT_END_Q03 + 2 * HSTEPS)>();
         } else {
-            wait_vm<WAIT_END>();
+            wait_vm<WAIT_END_Q03>();
         }
         __syncthreads();
     }
