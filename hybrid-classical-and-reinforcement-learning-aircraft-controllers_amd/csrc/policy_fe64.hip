@@ -192,7 +192,10 @@ policy_fe64_kernel(const float* __restrict__ obs /*[B][18]*/, const uint8_t* __r
 
     // one unit: NG gates x KS k-steps x 2 tiles MFMAs from LDS buffer `buf`; after MFMA m the next chunk's DMA slot (while
     // any are left) and the micro-stages [m U / M, (m + 1) U / M) of `micro`
-    auto unit = [&](auto ks_c, auto ng_c, auto in_c, int buf, auto& acc_of, auto nmicro_c, auto&& micro, int noff, int nnp, int nbuf) {
+    // `pre` runs at the top of the unit, behind the first weight-fragment reads: the epilogue's bias reads go there, once per
+    // unit (round 3: read inside the micro-stages, each one was followed at once by its use -- an LDS round trip per group, 16 per
+    // unit, with nothing but this wave on the SIMD to cover it)
+    auto unit = [&](auto ks_c, auto ng_c, auto in_c, int buf, auto& acc_of, auto nmicro_c, auto&& micro, int noff, int nnp, int nbuf, auto&& pre) {
         constexpr int KS = decltype(ks_c)::value, NG = decltype(ng_c)::value, IN = decltype(in_c)::value;
         constexpr int M = KS * NG * 2, U = decltype(nmicro_c)::value;
         constexpr int EVERY = M / NPW_MAX >= 3 ? 3 : (M / NPW_MAX >= 1 ? M / NPW_MAX : 1);
@@ -200,6 +203,7 @@ policy_fe64_kernel(const float* __restrict__ obs /*[B][18]*/, const uint8_t* __r
         bf16x8_t w[2][NG];
 #pragma unroll
         for (int g = 0; g < NG; ++g) w[0][g] = wfrag(buf, RB, 32 * g, 0);
+        pre();
         FENCE();
         sfor<0, KS>([&](auto KSI) {
             constexpr int ks = decltype(KSI)::value;
@@ -220,6 +224,7 @@ policy_fe64_kernel(const float* __restrict__ obs /*[B][18]*/, const uint8_t* __r
     constexpr int NS = 11;                              // micro-stages per group in both epilogues
     constexpr int NMICRO = 8 * NS;
     struct GS { f32x4_t b0, b1; float x[4], y[4], z[4]; };
+    f32x4_t pb0[4], pb1[4];                             // the unit's epilogue biases for groups q = 0..3 (both row tiles share them)
 
     auto layer = [&](auto ks_c, auto in_c, auto out_c, int sb, int off0, int next_off, int next_np) {
         constexpr int KS = decltype(ks_c)::value, IN = decltype(in_c)::value, OUT = decltype(out_c)::value;
@@ -232,8 +237,8 @@ policy_fe64_kernel(const float* __restrict__ obs /*[B][18]*/, const uint8_t* __r
             constexpr int t = gq >> 2, q = gq & 3;
             GS& s = gs[gq];
             if constexpr (st == 0) {
-                s.b0 = *reinterpret_cast<const f32x4_t*>(&s_b[sb + 32 * sl + 8 * q + 4 * hf]);
-                s.b1 = *reinterpret_cast<const f32x4_t*>(&s_b[sb + 2 * H + 32 * sl + 8 * q + 4 * hf]);
+                s.b0 = pb0[q];
+                s.b1 = pb1[q];
             } else if constexpr (st == 1) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.x[i] = __builtin_fmaf(aA[0][t][4 * q + i], -L2E, s.b0[i]); });
             } else if constexpr (st == 2) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.x[i] = ex2(s.x[i]); });
             } else if constexpr (st == 3) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.y[i] = __builtin_fmaf(aA[1][t][4 * q + i], -2.0f * L2E, s.b1[i]); });
@@ -250,7 +255,7 @@ policy_fe64_kernel(const float* __restrict__ obs /*[B][18]*/, const uint8_t* __r
             constexpr int u = decltype(UU)::value, pr = u / (2 * NS), st = (u % (2 * NS)) / 2, gq = 2 * pr + (u & 1);
             constexpr int t = gq >> 2, q = gq & 3;
             GS& s = gs[gq];
-            if constexpr (st == 0) { s.b0 = *reinterpret_cast<const f32x4_t*>(&s_b[sb + 3 * H + 32 * psl + 8 * q + 4 * hf]);
+            if constexpr (st == 0) { s.b0 = pb0[q];
             } else if constexpr (st == 1) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.x[i] = __builtin_fmaf(aB[t][4 * q + i], -L2E, s.b0[i]); });
             } else if constexpr (st == 2) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.x[i] = ex2(s.x[i]); });
             } else if constexpr (st == 3) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.y[i] = ig[t][4 * q + i] * (-2.0f * L2E); });
@@ -282,20 +287,33 @@ policy_fe64_kernel(const float* __restrict__ obs /*[B][18]*/, const uint8_t* __r
         for (int sl = 0; sl < 8; ++sl) {
             const int off_ig = off0 + sl * (NP_IG + NP_O), off_o = off_ig + NP_IG;
             // P0: (i, g) of slice sl from buffer 1 -> aA ; under it the o epilogue of slice sl - 1 ; request (sl, o) -> buffer 0
-            if (sl == 0) unit(ks_c, IC<2>{}, in_c, 1, accA, IC<0>{}, [&](auto) {}, off_o, 0, 0);        // its o chunk was requested before the layer
-            else unit(ks_c, IC<2>{}, in_c, 1, accA, IC<NMICRO>{}, h_micro, off_o, NP_O, 0);
+            auto pre_h = [&]() {                        // o-gate biases of the pending slice
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pb0[q] = *reinterpret_cast<const f32x4_t*>(&s_b[sb + 3 * H + 32 * psl + 8 * q + 4 * hf]);
+            };
+            auto pre_ig = [&]() {                       // (i, g) biases of this slice
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    pb0[q] = *reinterpret_cast<const f32x4_t*>(&s_b[sb + 32 * sl + 8 * q + 4 * hf]);
+                    pb1[q] = *reinterpret_cast<const f32x4_t*>(&s_b[sb + 2 * H + 32 * sl + 8 * q + 4 * hf]);
+                }
+            };
+            if (sl == 0) unit(ks_c, IC<2>{}, in_c, 1, accA, IC<0>{}, [&](auto) {}, off_o, 0, 0, [] {});        // its o chunk was requested before the layer
+            else unit(ks_c, IC<2>{}, in_c, 1, accA, IC<NMICRO>{}, h_micro, off_o, NP_O, 0, pre_h);
             if (sl > 0) commit();
             wait_vm0();
             __syncthreads();
             // P1: o of slice sl from buffer 0 -> aB ; under it the (i, g) epilogue of slice sl ; request the next (i, g) chunk
             // (past the layer: the next layer's first chunk) -> buffer 1
             const int noff = sl < 7 ? off_ig + NP_IG + NP_O : next_off, nnp = sl < 7 ? NP_IG : next_np;
-            unit(ks_c, IC<1>{}, in_c, 0, accB, IC<NMICRO>{}, [&](auto UU) { ig_micro(sl, UU); }, noff, nnp, 1);
+            unit(ks_c, IC<1>{}, in_c, 0, accB, IC<NMICRO>{}, [&](auto UU) { ig_micro(sl, UU); }, noff, nnp, 1, pre_ig);
             psl = sl;
             wait_vm0();
             __syncthreads();
         }
         // drain: the last slice's o epilogue has nothing to hide under
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pb0[q] = *reinterpret_cast<const f32x4_t*>(&s_b[sb + 3 * H + 32 * psl + 8 * q + 4 * hf]);
         sfor<0, NMICRO>([&](auto UU) { h_micro(UU); });
         commit();
     };
