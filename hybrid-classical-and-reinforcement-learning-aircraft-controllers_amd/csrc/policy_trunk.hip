@@ -117,10 +117,8 @@ policy_trunk_kernel(const uint16_t* __restrict__ h_pi, const uint16_t* __restric
     // as the current one has been written to LDS: all 1024 waves of the launch run in phase (one per SIMD), so an un-prefetched
     // tile is a 17 MB burst that every wave waits for, four times per launch (piece p = 64 i + lane: row p / 32, 16-byte
     // column p % 32; rows past the end read the last row).
-    // TWO tiles in flight per wave (round 3: with one, a wave waited ~3 us for its next 16 KB four times per launch -- the
-    // kernel moved 67 MB in 30 us): tile k + 2 is requested as soon as tile k has been written to LDS.
-    u32x4_t pa[K1 / 16], pb[K1 / 16];
-    auto request = [&](u32x4_t (&pieces)[K1 / 16], int64_t first) {
+    u32x4_t pieces[K1 / 16];
+    auto request = [&](int64_t first) {
         sfor<0, K1 / 16>([&](auto I) {
             constexpr int i = decltype(I)::value;
             const int pc = 64 * i + lane, prow = pc >> 5, pcol = pc & 31;
@@ -128,20 +126,18 @@ policy_trunk_kernel(const uint16_t* __restrict__ h_pi, const uint16_t* __restric
             pieces[i] = *reinterpret_cast<const u32x4_t*>(h + src * K1 + pcol * 8);
         });
     };
-    const int64_t w_first = wg_first + wave * 32;
-    if (w_first < wg_end) request(pa, w_first);
-    if (w_first + 128 < wg_end) request(pb, w_first + 128);
-    auto tile = [&](u32x4_t (&pieces)[K1 / 16], int64_t row0) {
+    if (wg_first + wave * 32 < wg_end) request(wg_first + wave * 32);
+    for (int64_t row0 = wg_first + wave * 32; row0 < wg_end; row0 += 128) {          // wave-uniform
         const int64_t my_row = row0 + r;
         uint16_t* sh = s_h[wave];
-        // (a wave's LDS operations execute in program order: the previous tile's fragment reads precede these writes, the
+        // (a wave's LDS operations execute in program order: the previous iteration's fragment reads precede these writes, the
         // reads below follow them -- no barrier, the region is this wave's own)
         sfor<0, K1 / 16>([&](auto I) {
             constexpr int i = decltype(I)::value;
             const int pc = 64 * i + lane, prow = pc >> 5, pcol = pc & 31;
             *reinterpret_cast<u32x4_t*>(sh + prow * ROW1 + pcol * 8) = pieces[i];
         });
-        if (row0 + 256 < wg_end) request(pieces, row0 + 256);
+        if (row0 + 128 < wg_end) request(row0 + 128);
         // ---- layer-1 B fragments: lane (b, hf) holds h[b][16 s + 8 hf .. + 7] for every k-step s
         bf16x8_t bx[K1 / 16];
         const uint16_t* hr = sh + r * ROW1 + 8 * hf;
@@ -275,10 +271,6 @@ policy_trunk_kernel(const uint16_t* __restrict__ h_pi, const uint16_t* __restric
                 }
             }
         }
-    };
-    for (int64_t row0 = w_first; row0 < wg_end; row0 += 256) {          // wave-uniform
-        tile(pa, row0);
-        if (row0 + 128 < wg_end) tile(pb, row0 + 128);
     }
 }
 
