@@ -860,3 +860,46 @@ def test_heads_behind_the_trunks_equal_the_two_launch_path(B, monkeypatch):
     assert (a1 - a0).abs().max() < 2e-5 and (v1 - v0).abs().max() < 2e-5 and torch.equal(lp1, lp0)
     assert (a1 - ad).abs().max() > 0.1 and (a1.std(0) > 0.3).all()          # really sampled, really different per row
     assert torch.equal(vd, v1)
+
+
+def test_episode_flags_moves_the_noise_counter_for_any_flag_dtype():
+    """The glue between an env step and the next policy step advances the action-noise counter whatever dtype the env's done
+    flags have (uint8: one fused launch; bool: the tensor-op fallback) -- a counter that stops would replay the same noise on
+    every step of every rollout with no error raised."""
+    from hcrl_amd.fused import episode_flags
+    n = 1000
+    for dt in (torch.uint8, torch.bool):
+        term = (torch.rand(n, device="cuda") < 0.1).to(dt)
+        trunc = (torch.rand(n, device="cuda") < 0.1).to(dt)
+        start, keep = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        counter = torch.zeros(1, dtype=torch.int32, device="cuda")
+        for k in range(3):
+            episode_flags(term, trunc, start, keep, counter)
+        done = (term.bool() | trunc.bool()).float()
+        assert int(counter) == 3 and torch.equal(start, done) and torch.equal(keep, 1.0 - done)
+
+
+def test_event_capacity_is_whole_shards_or_refused():
+    """Episode-end records live in FD_EV_SHARDS segments of ev_cap / FD_EV_SHARDS records: the C entry refuses a capacity that
+    would give segments of zero records (it used to drop every record silently), the host class rounds a caller's figure up."""
+    from hcrl_amd import _lib, layout as L
+    from hcrl_amd.rate_env import GpuRateVecEnv
+    env = GpuRateVecEnv(10, "medium", 10.0, 0.02, "step", seed=0, precision="mixed", event_capacity=10)
+    assert env.ev_cap % L.FD_EV_SHARDS == 0 and env.ev_cap >= L.FD_EV_SHARDS and env._ev_cap_shard >= 1
+    env.reset()
+    a = torch.zeros((10, 4), device=env.device)
+    a[:, 0] = 1.0                                           # hard-over aileron: every env crashes within the episode
+    ends = 0
+    for _ in range(400):
+        env.step_device(a)
+        ints, _ = env.episode_events()
+        ends += ints.shape[0]
+    assert ends >= 10                                       # records were kept, not dropped
+    lib = _lib.load()
+    fn = lib.fdyn_rate_env_step_mixed
+    cur, nxt = env._ev_counts[0], env._ev_counts[1]
+    args = [env.x.data_ptr(), env.e.data_ptr(), env.ei.data_ptr(), None, env.params.data_ptr(), env.n_types, env.env_consts.data_ptr(),
+            a.data_ptr(), env.pid_state.data_ptr(), env.pid_cfg.data_ptr(), env.casc_consts.data_ptr(), None, None, None, 1, 0, 1, 0.0,
+            env.obs.data_ptr(), env.rewards.data_ptr(), env.rewards_full.data_ptr(), env.terminated.data_ptr(), env.truncated.data_ptr(),
+            cur.data_ptr(), nxt.data_ptr(), env.ev_int.data_ptr(), env.ev_flt.data_ptr(), 10, env.n, _lib.current_stream()]
+    assert fn(*args) == _lib.FDYN_ERR_BAD_SIZE
