@@ -205,14 +205,16 @@ class Workload:
         from hcrl_amd.fused import episode_flags
         nxt = p._state_bufs[1 - p._cur]
         fused_glue = p.policy._fused_ok(p.obs)
-        a, _v, _lp, new_states = p.policy.step(p.obs, p.states, p.episode_start, out_states=nxt, keep=p.keep, bump_noise=not fused_glue)
+        # the previous step's done flags -> episode_start / keep / noise counter inside the step's first kernel (as RecurrentPPO._rollout_body)
+        a, _v, _lp, new_states = p.policy.step(p.obs, p.states, p.episode_start, out_states=nxt, keep=p.keep, bump_noise=not fused_glue,
+                                               done_flags=(self.env.terminated, self.env.truncated) if fused_glue else None)
         _obs, _r, term, trunc = self.env.step_device(a)          # p.obs aliases the env's observation buffer
         for dst, src in zip(nxt, new_states):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src)
         p._cur = 1 - p._cur
-        # episode_start, keep = 1 - episode_start and the action-noise counter in one launch (as RecurrentPPO._rollout_body)
-        episode_flags(term, trunc, p.episode_start, p.keep, p.policy.noise_counter(p.device) if fused_glue else None)
+        if not fused_glue:
+            episode_flags(term, trunc, p.episode_start, p.keep, None)
 
     def step(self, k):
         if self.kind == "rollout":

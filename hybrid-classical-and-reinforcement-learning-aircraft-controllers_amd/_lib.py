@@ -57,6 +57,7 @@ SIGNATURES = {
     "fdyn_policy_recurrent": (_i, [_p] * 12 + [_i64, _p]),
     "fdyn_policy_features_image_bytes": (_i, []),
     "fdyn_policy_features": (_i, [_p, _p, _p, _p, _i64, _p]),
+    "fdyn_policy_features_flags": (_i, [_p] * 9 + [_i64, _p]),
     "fdyn_gaussian_head": (_i, [_p, _i, _p, _u64, _p, _i, _p, _p, _i64, _p]),
     "fdyn_policy_heads": (_i, [_p, _p, _p, _p, _p, _p, _p, _u64, _p, _i, _p, _p, _p, _i64, _p]),
     "fdyn_gae": (_i, [_p, _p, _p, _p, _p, _f, _f, _i, _i64, _p, _p, _p]),

@@ -93,10 +93,14 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi)
 __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
+// the glue between the previous env step and this policy step (what fdyn_episode_flags does in a launch of its own), done by
+// the first kernel of the step: thread = row
+struct FlagArgs { const uint8_t* term; const uint8_t* trunc; float* episode_start; float* keep; int32_t* counter; };
+
 __global__ void __launch_bounds__(256, 1)
 policy_fe64_kernel(const float* __restrict__ obs /*[B][18]*/, const uint8_t* __restrict__ wimg /*[IMG_PIECES][1024]*/,
                    const float* __restrict__ bias /*[128 + 1024 + 1024 + 128]: embedding, layer 1, layer 2, projection*/,
-                   uint16_t* __restrict__ feats /*[B][128] bf16*/)
+                   uint16_t* __restrict__ feats /*[B][128] bf16*/, FlagArgs fl)
 {
     constexpr int OROW = 2 * FEAT + 16;                 // padded row of the output staging tile (bytes)
     __shared__ __attribute__((aligned(16))) uint8_t s_w[2 * BUFB];
@@ -124,6 +128,14 @@ policy_fe64_kernel(const float* __restrict__ obs /*[B][18]*/, const uint8_t* __r
     };
     req_all(0, NP_EMB, 0);
     req_all(OFF_A, NP_A_IG, 1);
+
+    if (fl.term) {                                      // episode_start / keep of this step's rows, the action-noise counter
+        const int64_t row = int64_t(blockIdx.x) * 256 + tid;
+        const bool done = (fl.term[row] | fl.trunc[row]) != 0;
+        if (fl.episode_start) fl.episode_start[row] = done ? 1.0f : 0.0f;
+        if (fl.keep) fl.keep[row] = done ? 0.0f : 1.0f;
+        if (fl.counter && blockIdx.x == 0 && tid == 0) fl.counter[0] += 1;
+    }
 
     // ---- biases -> LDS, pre-scaled for the exponent forms below: i, o: -log2 e; g: -2 log2 e; Linear layers: 1
     for (int i = tid; i < EMB + 8 * H + FEAT; i += 256) {
@@ -372,6 +384,17 @@ extern "C" int fdyn_policy_features(const float* obs, const void* weight_image, 
     if (!obs || !weight_image || !bias || !feats) return FDYN_ERR_NULL;
     if (B <= 0 || B % 256) return FDYN_ERR_BAD_SIZE;
     hipLaunchKernelGGL(policy_fe64_kernel, dim3(unsigned(B / 256)), dim3(256), 0, (hipStream_t)stream,
-                       obs, (const uint8_t*)weight_image, bias, (uint16_t*)feats);
+                       obs, (const uint8_t*)weight_image, bias, (uint16_t*)feats, FlagArgs{});
+    return int(hipGetLastError());
+}
+
+extern "C" int fdyn_policy_features_flags(const float* obs, const void* weight_image, const float* bias, void* feats,
+                                          const uint8_t* terminated, const uint8_t* truncated, float* episode_start, float* keep,
+                                          int32_t* counter, int64_t B, void* stream)
+{
+    if (!obs || !weight_image || !bias || !feats || !terminated || !truncated) return FDYN_ERR_NULL;
+    if (B <= 0 || B % 256) return FDYN_ERR_BAD_SIZE;
+    hipLaunchKernelGGL(policy_fe64_kernel, dim3(unsigned(B / 256)), dim3(256), 0, (hipStream_t)stream,
+                       obs, (const uint8_t*)weight_image, bias, (uint16_t*)feats, FlagArgs{terminated, truncated, episode_start, keep, counter});
     return int(hipGetLastError());
 }

@@ -315,10 +315,13 @@ class RateLSTMPolicy(nn.Module):
         return (inf is not None and obs.is_cuda and self.compute_dtype == torch.bfloat16 and not torch.is_grad_enabled()
                 and self.hidden == 256 and all(w.shape[1] in (128, 256) for w in inf["fe_w"]))
 
-    def _core_fused(self, obs, states: RNNStates, keep, out_states: Optional[RNNStates] = None, heads: Optional[dict] = None):
+    def _core_fused(self, obs, states: RNNStates, keep, out_states: Optional[RNNStates] = None, heads: Optional[dict] = None,
+                    flags: Optional[tuple] = None):
         """Explicit bf16 inference path (no autocast): pre-cast Linear weights + one MFMA kernel per LSTM cell.
         heads = {"deterministic": bool}: where the trunk kernel serves the shape, the output heads and the sampling run behind
-        the trunks in the same launch and the return value is (actions, value, logp, new_states)."""
+        the trunks in the same launch and the return value is (actions, value, logp, new_states).
+        flags = (terminated, truncated, episode_start, keep, counter): the glue between the previous env step and this step, done
+        by the features kernel for its rows (else by fused.episode_flags in a launch of its own, before anything reads keep)."""
         from . import _lib
         lib, inf, B, H = _lib.load(), self._inf, obs.shape[0], self.hidden
         bf, dev = torch.bfloat16, obs.device
@@ -332,9 +335,26 @@ class RateLSTMPolicy(nn.Module):
             assert o32.shape == (B, OBS_DIM) and inf["fe_img"].numel() * 2 == lib.fdyn_policy_features_image_bytes() \
                 and inf["fe_bias"].numel() == 128 + 1024 + 1024 + 128, "policy_features operand shapes"
             feats = torch.empty((B, 128), dtype=bf, device=dev)
-            _lib.check(lib.fdyn_policy_features(o32.data_ptr(), inf["fe_img"].data_ptr(), inf["fe_bias"].data_ptr(),
-                                                feats.data_ptr(), B, st), "policy_features")
+            if flags is not None and flags[0].dtype == torch.uint8 and flags[1].dtype == torch.uint8:
+                term, trunc, es, kp, ctr = flags
+                assert term.shape == (B,) and trunc.shape == (B,) and es.shape == (B,) and kp.shape == (B,) and es.dtype == torch.float32 \
+                    and kp.dtype == torch.float32 and all(t.is_contiguous() for t in (term, trunc, es, kp)), "policy_features_flags operands"
+                _lib.check(lib.fdyn_policy_features_flags(o32.data_ptr(), inf["fe_img"].data_ptr(), inf["fe_bias"].data_ptr(), feats.data_ptr(),
+                                                          term.data_ptr(), trunc.data_ptr(), es.data_ptr(), kp.data_ptr(), _lib.ptr(ctr), B, st),
+                           "policy_features_flags")
+                flags = None
+            else:
+                if flags is not None:
+                    from .fused import episode_flags
+                    episode_flags(*flags)
+                    flags = None
+                _lib.check(lib.fdyn_policy_features(o32.data_ptr(), inf["fe_img"].data_ptr(), inf["fe_bias"].data_ptr(),
+                                                    feats.data_ptr(), B, st), "policy_features")
         else:
+            if flags is not None:
+                from .fused import episode_flags
+                episode_flags(*flags)
+                flags = None
             x = self._mlp_bf16(obs.to(bf), inf["emb"])
             for w, b in zip(inf["fe_w"], inf["fe_b"]):                   # zero-state layers: no h/c input at all
                 assert shapes_ok(x, w, b, 0), "lstm_cell_mfma operand shapes"
@@ -403,20 +423,27 @@ class RateLSTMPolicy(nn.Module):
         return self._noise_step
 
     def step(self, obs, states: RNNStates, episode_start, deterministic: bool = False,
-             out_states: Optional[RNNStates] = None, keep: Optional[torch.Tensor] = None, bump_noise: bool = True):
+             out_states: Optional[RNNStates] = None, keep: Optional[torch.Tensor] = None, bump_noise: bool = True,
+             done_flags: Optional[tuple] = None):
         """obs [B,18], episode_start [B] (1 where the env was just reset) -> actions, values, log_probs, new states.
         keep: 1 - episode_start if the caller already has it (fused.episode_flags writes both); bump_noise=False: the caller
-        moves the noise counter on itself (the same launch) -- a rollout loop then has no framework glue launches left."""
+        moves the noise counter on itself (the same launch) -- a rollout loop then has no framework glue launches left.
+        done_flags = (terminated, truncated) of the PREVIOUS env step (fused path only, with `keep` given): episode_start and keep
+        are REWRITTEN from them and the noise counter moves on inside the step's first kernel."""
         if self._fused_ok(obs):
             if keep is None:
+                assert done_flags is None, "done_flags needs the caller's keep buffer"
                 keep = (1.0 - episode_start.float()).contiguous()        # the mask is applied inside the kernel
             # output heads + sampling + log-prob ride behind the trunks (or in ONE launch of their own): in-kernel Philox keyed
             # by a per-policy seed, the env index and a step counter that lives on the device, so a captured graph draws fresh
             # noise on every replay
             self.noise_counter(obs.device)
-            if bump_noise:
+            fl = None
+            if done_flags is not None:
+                fl = (done_flags[0], done_flags[1], episode_start, keep, self._noise_step)
+            elif bump_noise:
                 self._noise_step.add_(1)
-            res = self._core_fused(obs, states, keep, out_states, heads={"deterministic": deterministic})
+            res = self._core_fused(obs, states, keep, out_states, heads={"deterministic": deterministic}, flags=fl)
             if len(res) == 4:
                 return res
             lat_pi, lat_vf, new_states = res

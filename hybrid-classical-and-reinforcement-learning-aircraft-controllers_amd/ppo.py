@@ -169,6 +169,8 @@ class RecurrentPPO:
         # time-limit bootstrap term gamma * V(.), kept OUT of buf_rew: GAE sees rew + boot, the logs see the env's own rewards
         self.buf_boot = torch.zeros((T, N), **f32) if self.cfg.bootstrap_timeouts else None
         self.obs = env.reset()                           # aliases the env's observation buffer (rewritten every step)
+        if hasattr(env, "mark_episode_starts"):
+            env.mark_episode_starts()
         self._alloc_states(N)
         self.episode_start = torch.ones(N, **f32)
         self.keep = torch.zeros(N, **f32)                # 1 - episode_start, kept in step by fused.episode_flags
@@ -203,6 +205,8 @@ class RecurrentPPO:
         assert env.num_envs == self.env.num_envs
         self.env = env
         self.obs = env.reset()
+        if hasattr(env, "mark_episode_starts"):
+            env.mark_episode_starts()
         for t in self.states:
             t.zero_()
         self.episode_start.fill_(1.0)
@@ -217,10 +221,14 @@ class RecurrentPPO:
         # the fused policy path + uint8 env flags: episode_start, keep and the action-noise counter move in ONE launch per step
         fused_glue = self.device.type == "cuda" and pol._fused_ok(self.obs)
         counter = pol.noise_counter(self.device) if fused_glue else None
+        # where the env hands out uint8 done flags in fixed buffers, the step's FIRST kernel turns the previous step's flags into
+        # episode_start / keep and moves the noise counter on (policy.step: done_flags): no glue launch between the steps
+        in_step = fused_glue and all(getattr(getattr(env, k, None), "dtype", None) == torch.uint8 for k in ("terminated", "truncated"))
         for t in range(cfg.n_steps):
             nxt = self._state_bufs[1 - self._cur]             # the fused cells write the new state straight into it
             actions, values, logp, new_states = pol.step(self.obs, self.states, self.episode_start, out_states=nxt,
-                                                         keep=self.keep, bump_noise=not fused_glue)
+                                                         keep=self.keep, bump_noise=not fused_glue,
+                                                         done_flags=(env.terminated, env.truncated) if in_step else None)
             self.buf_obs[t].copy_(self.obs); self.buf_act[t].copy_(actions); self.buf_val[t].copy_(values)
             self.buf_logp[t].copy_(logp); self.buf_start[t].copy_(self.episode_start)
             obs, rew, term, trunc = env.step_device(actions)          # clip happens in-kernel (rate_env.py:225)
@@ -252,7 +260,10 @@ class RecurrentPPO:
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src)                                # un-fused policy paths return fresh tensors
             self._cur = 1 - self._cur
-            if fused_glue:                                        # any flag dtype: its tensor-op fallback bumps the counter too
+            if in_step:
+                if t == cfg.n_steps - 1:                          # after the last step: the flags GAE and predict_values read
+                    episode_flags(term, trunc, self.episode_start, self.keep, None)
+            elif fused_glue:                                      # any flag dtype: its tensor-op fallback bumps the counter too
                 episode_flags(term, trunc, self.episode_start, self.keep, counter)
             else:
                 self.episode_start.copy_((term | trunc).float())

@@ -137,6 +137,12 @@ class GpuRateVecEnv:
             self.sensor.apply(self.obs, mask)
         return self.obs, self.rewards, self.terminated, self.truncated
 
+    def mark_episode_starts(self):
+        """After a reset every env is at the start of an episode: say so in the done flags a rollout loop reads as "the previous
+        step ended an episode" (SB3's `_last_episode_starts = ones`); the next step overwrites them."""
+        self.terminated.fill_(1)
+        self.truncated.zero_()
+
     def step(self, actions, auto_reset: bool = True):
         if isinstance(actions, np.ndarray):
             if self.numpy_io and actions.shape == (self.n, L.FD_ACT_DIM):        # pinned staging: one async H2D, no pageable copy

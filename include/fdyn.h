@@ -282,6 +282,12 @@ int fdyn_lstm_cell_mfma_train(const void* x, int kx, const void* h_prev, int kh,
  * bias [128 + 1024 + 1024 + 128] fp32 = embedding, b_ih + b_hh of layer 1 and 2, projection.  B % 256 == 0.               */
 int fdyn_policy_features_image_bytes(void);
 int fdyn_policy_features(const float* obs, const void* weight_image, const float* bias, void* feats, int64_t B, void* stream);
+/* The same launch also doing the rollout glue of fdyn_episode_flags for its rows (terminated / truncated [B] uint8 of the
+ * PREVIOUS env step -> episode_start [B], keep [B] fp32, either may be NULL; *counter += 1, NULL = none): the cells launched
+ * behind it read keep, the heads read the counter -- one launch less per rollout step.                                      */
+int fdyn_policy_features_flags(const float* obs, const void* weight_image, const float* bias, void* feats,
+                               const uint8_t* terminated, const uint8_t* truncated, float* episode_start, float* keep,
+                               int32_t* counter, int64_t B, void* stream);
 /* Diagonal-Gaussian policy head: actions [B][4] = mean + exp(log_std) * N(0,1) (Philox keyed by seed, env, *step -- a
  * uint32 counter in DEVICE memory the caller increments on the stream, so graph replays draw fresh noise; or the mean
  * itself when deterministic), logp [B] = log-probability of the sampled action.  mean [B][4] bf16 (mean_bf16=1) or fp32. */

@@ -903,3 +903,37 @@ def test_event_capacity_is_whole_shards_or_refused():
             env.obs.data_ptr(), env.rewards.data_ptr(), env.rewards_full.data_ptr(), env.terminated.data_ptr(), env.truncated.data_ptr(),
             cur.data_ptr(), nxt.data_ptr(), env.ev_int.data_ptr(), env.ev_flt.data_ptr(), 10, env.n, _lib.current_stream()]
     assert fn(*args) == _lib.FDYN_ERR_BAD_SIZE
+
+
+@pytest.mark.parametrize("B", [512, 65536])
+def test_done_flags_inside_the_policy_step_equal_the_glue_launch(B):
+    """policy.step(done_flags=(terminated, truncated)) -- the previous env step's flags turned into episode_start / keep and the
+    noise counter moved on by the step's FIRST kernel (fdyn_policy_features_flags; a launch of fused.episode_flags where that
+    kernel does not serve the batch) -- against fused.episode_flags followed by a plain step: same masks, same counter, same
+    actions (same noise), same new state."""
+    from hcrl_amd.fused import episode_flags
+    from hcrl_amd.policy import RNNStates
+    torch.manual_seed(5)
+    p = RateLSTMPolicy(compute_dtype=torch.bfloat16).cuda()
+    with torch.no_grad():
+        p.action_net.weight.mul_(30.0)
+    p.prepare_inference()
+    obs = torch.randn(B, 18, device="cuda")
+    mk = lambda: RNNStates(*(torch.randn(B, 256, device="cuda").to(dt) * 0.5 for dt in (torch.bfloat16, torch.float32) * 2))  # noqa: E731
+    st = mk()
+    term = (torch.rand(B, device="cuda") < 0.05).to(torch.uint8)
+    trunc = (torch.rand(B, device="cuda") < 0.05).to(torch.uint8)
+    ctr = p.noise_counter("cuda")
+    ctr.fill_(7)
+    es0, kp0 = torch.full((B,), 0.5, device="cuda"), torch.full((B,), 0.5, device="cuda")       # garbage: must be overwritten
+    with torch.no_grad():
+        a1, v1, lp1, s1 = p.step(obs, st, es0, keep=kp0, bump_noise=False, done_flags=(term, trunc))
+    c1 = int(ctr)
+    ctr.fill_(7)
+    es1, kp1 = torch.zeros(B, device="cuda"), torch.zeros(B, device="cuda")
+    episode_flags(term, trunc, es1, kp1, ctr)
+    with torch.no_grad():
+        a0, v0, lp0, s0 = p.step(obs, st, es1, keep=kp1, bump_noise=False)
+    done = ((term | trunc) != 0).float()
+    assert c1 == 8 and int(ctr) == 8 and torch.equal(es0, done) and torch.equal(kp0, 1.0 - done) and torch.equal(es0, es1)
+    assert torch.equal(a1, a0) and torch.equal(v1, v0) and torch.equal(lp1, lp0) and all(torch.equal(x, y) for x, y in zip(s1, s0))
