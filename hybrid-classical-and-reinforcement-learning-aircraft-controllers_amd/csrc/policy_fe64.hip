@@ -233,9 +233,10 @@ policy_fe64_kernel(const float* __restrict__ obs /*[B][18]*/, const uint8_t* __r
     };
 
     // micro-stage order: groups in pairs, the two groups of a pair alternate (dependent operations sit eight instructions apart)
-    constexpr int NS = 11;                              // micro-stages per group in both epilogues
+    constexpr int NS = 9;                               // micro-stages per group in both epilogues (round 3: 11 -- the bias copy and
+                                                        // the separate 1 - x stages are gone: (1 - G) z = fma(-G, z, z))
     constexpr int NMICRO = 8 * NS;
-    struct GS { f32x4_t b0, b1; float x[4], y[4], z[4]; };
+    struct GS { float x[4], y[4], z[4]; };
     f32x4_t pb0[4], pb1[4];                             // the unit's epilogue biases for groups q = 0..3 (both row tiles share them)
 
     auto layer = [&](auto ks_c, auto in_c, auto out_c, int sb, int off0, int next_off, int next_np) {
@@ -248,35 +249,29 @@ policy_fe64_kernel(const float* __restrict__ obs /*[B][18]*/, const uint8_t* __r
             constexpr int u = decltype(UU)::value, pr = u / (2 * NS), st = (u % (2 * NS)) / 2, gq = 2 * pr + (u & 1);
             constexpr int t = gq >> 2, q = gq & 3;
             GS& s = gs[gq];
-            if constexpr (st == 0) {
-                s.b0 = pb0[q];
-                s.b1 = pb1[q];
-            } else if constexpr (st == 1) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.x[i] = __builtin_fmaf(aA[0][t][4 * q + i], -L2E, s.b0[i]); });
-            } else if constexpr (st == 2) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.x[i] = ex2(s.x[i]); });
-            } else if constexpr (st == 3) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.y[i] = __builtin_fmaf(aA[1][t][4 * q + i], -2.0f * L2E, s.b1[i]); });
-            } else if constexpr (st == 4) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.y[i] = __builtin_amdgcn_fmed3f(s.y[i], -40.0f, 40.0f); });
-            } else if constexpr (st == 5) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.y[i] = ex2(s.y[i]); });
-            } else if constexpr (st == 6) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.z[i] = 1.0f + s.y[i]; });
-            } else if constexpr (st == 7) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.z[i] = __builtin_fmaf(s.z[i], s.x[i], s.z[i]); });
-            } else if constexpr (st == 8) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.z[i] = rcp(s.z[i]); });
-            } else if constexpr (st == 9) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.y[i] = 1.0f - s.y[i]; });
-            } else { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; ig[t][4 * q + i] = s.y[i] * s.z[i]; }); }
+            if constexpr (st == 0) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.x[i] = __builtin_fmaf(aA[0][t][4 * q + i], -L2E, pb0[q][i]); });
+            } else if constexpr (st == 1) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.x[i] = ex2(s.x[i]); });
+            } else if constexpr (st == 2) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.y[i] = __builtin_fmaf(aA[1][t][4 * q + i], -2.0f * L2E, pb1[q][i]); });
+            } else if constexpr (st == 3) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.y[i] = __builtin_amdgcn_fmed3f(s.y[i], -40.0f, 40.0f); });
+            } else if constexpr (st == 4) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.y[i] = ex2(s.y[i]); });
+            } else if constexpr (st == 5) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.z[i] = 1.0f + s.y[i]; });
+            } else if constexpr (st == 6) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.z[i] = __builtin_fmaf(s.z[i], s.x[i], s.z[i]); });
+            } else if constexpr (st == 7) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.z[i] = rcp(s.z[i]); });
+            } else { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; ig[t][4 * q + i] = __builtin_fmaf(-s.y[i], s.z[i], s.z[i]); }); }
         };
         // o epilogue of the pending slice: h = sigmoid(o) tanh(c), c = ig in (-1, 1): h = (1 - E) / ((1 + E)(1 + O)), E = 2^(-2 c log2 e)
         auto h_micro = [&](auto UU) {
             constexpr int u = decltype(UU)::value, pr = u / (2 * NS), st = (u % (2 * NS)) / 2, gq = 2 * pr + (u & 1);
             constexpr int t = gq >> 2, q = gq & 3;
             GS& s = gs[gq];
-            if constexpr (st == 0) { s.b0 = pb0[q];
-            } else if constexpr (st == 1) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.x[i] = __builtin_fmaf(aB[t][4 * q + i], -L2E, s.b0[i]); });
-            } else if constexpr (st == 2) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.x[i] = ex2(s.x[i]); });
-            } else if constexpr (st == 3) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.y[i] = ig[t][4 * q + i] * (-2.0f * L2E); });
-            } else if constexpr (st == 4) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.y[i] = ex2(s.y[i]); });
-            } else if constexpr (st == 5) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.z[i] = 1.0f + s.y[i]; });
-            } else if constexpr (st == 6) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.z[i] = __builtin_fmaf(s.z[i], s.x[i], s.z[i]); });
-            } else if constexpr (st == 7) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.z[i] = rcp(s.z[i]); });
-            } else if constexpr (st == 8) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.y[i] = 1.0f - s.y[i]; });
-            } else if constexpr (st == 9) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.z[i] = s.y[i] * s.z[i]; });
+            if constexpr (st == 0) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.x[i] = __builtin_fmaf(aB[t][4 * q + i], -L2E, pb0[q][i]); });
+            } else if constexpr (st == 1) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.x[i] = ex2(s.x[i]); });
+            } else if constexpr (st == 2) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.y[i] = ig[t][4 * q + i] * (-2.0f * L2E); });
+            } else if constexpr (st == 3) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.y[i] = ex2(s.y[i]); });
+            } else if constexpr (st == 4) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.z[i] = 1.0f + s.y[i]; });
+            } else if constexpr (st == 5) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.z[i] = __builtin_fmaf(s.z[i], s.x[i], s.z[i]); });
+            } else if constexpr (st == 6) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.z[i] = rcp(s.z[i]); });
+            } else if constexpr (st == 7) { sfor<0, 4>([&](auto I) { constexpr int i = decltype(I)::value; s.z[i] = __builtin_fmaf(-s.y[i], s.z[i], s.z[i]); });
             } else { hp[t][2 * q] = pack2(s.z[0], s.z[1]); hp[t][2 * q + 1] = pack2(s.z[2], s.z[3]); }
         };
         // the pending slice's packed h -> output slab (the register index must be an immediate: one arm per slice)
