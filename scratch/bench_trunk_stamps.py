@@ -21,12 +21,14 @@ e0.record()
 for _ in range(50): run()
 e1.record(); torch.cuda.synchronize()
 print(f"trunks + heads: {e0.elapsed_time(e1) / 50 * 1e3:.1f} us")
-buf = np.zeros(512 * 32, np.uint64)
+buf = np.zeros(256 * 8 * 16, np.uint64)
 lib.fdyn_trunk_read_stamps(buf.ctypes.data_as(ctypes.c_void_p))
-s = buf.reshape(512, 32).astype(np.int64)
-s = s[s[:, 31] > 0]
-t0 = s[:, 0:1]
-names = ["start", "weights staged"] + [f"tile {i}: {n}" for i in range(4) for n in ("h in LDS", "layer 1 done", "layer 2 done", "heads done")]
-rel = np.median(s - t0, axis=0)
-for k, n in enumerate(names): print(f"  {n:26s} {rel[k]:8.0f} cycles")
-print(f"  {'end':26s} {rel[31]:8.0f} cycles   (spread of workgroup start: {np.percentile(s[:,0]-s[:,0].min(), 90):.0f} cycles p90)")
+s = buf.reshape(2, 128, 8, 16).astype(np.int64)
+names = ["start", "staging loads + row requests issued", "staging data arrived, LDS writes issued", "LDS writes done", "barrier passed"] + [f"tile {i}: {n}" for i in range(2) for n in ("rows in fragments", "layer 1 pass 0 done", "layer 1 pass 1 done", "layer 2 done", "heads done")]
+for trunk in range(2):
+    for grp, ws in (("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8))):
+        x = s[trunk, :, ws, :].reshape(-1, 16)
+        rel = np.median(x - x[:, 0:1], axis=0)
+        print(f"trunk {trunk} ({'pi' if trunk == 0 else 'vf'}), {grp}: " + "  ".join(f"{rel[k]:.0f}" for k in (0, 7, 13, 14, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12)) + f"  end {rel[15]:.0f}")
+print("columns: " + " | ".join(names))
+t0 = s[:, :, :, 0].min(); print(f"latest end over the launch: {(s[:, :, :, 15].max() - t0)} cycles; workgroup start spread p90: {np.percentile(s[:, :, 0, 0] - t0, 90):.0f}")
