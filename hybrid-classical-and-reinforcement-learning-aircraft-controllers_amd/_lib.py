@@ -52,6 +52,7 @@ SIGNATURES = {
     "fdyn_ppo_loss": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _f, _f, _i64, _p, _p, _p, _p, _p]),
     "fdyn_lstm_cell_mfma": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _p]),
     "fdyn_lstm_cell_mfma_inplace_ok": (_i, [_i, _i, _i, _i64]),
+    "fdyn_lstm_cell_mfma_pair": (_i, [_p, _i, _p, _i, _i64, _i] + [_p] * 13),
     "fdyn_lstm_cell_mfma_train": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i, _p]),
     "fdyn_policy_recurrent_image_bytes": (_i, []),
     "fdyn_policy_recurrent": (_i, [_p] * 12 + [_i64, _p]),

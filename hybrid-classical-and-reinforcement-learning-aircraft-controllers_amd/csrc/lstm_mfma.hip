@@ -504,6 +504,33 @@ extern "C" int fdyn_lstm_cell_mfma(const void* x, int kx, const void* h_prev, in
     return FDYN_ERR_BAD_SIZE;      // supported (input, recurrent) widths: (128,256) (128,0) (256,0) (128,128)
 }
 
+extern "C" int fdyn_lstm_cell_mfma64_pair_try(const void* x, int kx, const float* keep, int kh, int64_t B, int H,
+                                              const void* h_prev0, const float* c_prev0, const void* W0, const float* bias0, void* h_out0, float* c_out0,
+                                              const void* h_prev1, const float* c_prev1, const void* W1, const float* bias1, void* h_out1, float* c_out1,
+                                              void* stream);   // lstm_mfma64.hip
+
+// Two cells of the same shape on the same input and keep mask -- sb3_contrib's MlpLstmPolicy keeps an actor and a critic LSTM
+// (learned_controllers/networks/lstm_policy.py:107-136) -- in one launch where the one-wave-per-SIMD kernel applies, otherwise as
+// two calls of fdyn_lstm_cell_mfma.  Same operand rules (aliased state only where fdyn_lstm_cell_mfma_inplace_ok says so).
+extern "C" int fdyn_lstm_cell_mfma_pair(const void* x, int kx, const float* keep, int kh, int64_t B, int H,
+                                        const void* h_prev0, const float* c_prev0, const void* W0, const float* bias0, void* h_out0, float* c_out0,
+                                        const void* h_prev1, const float* c_prev1, const void* W1, const float* bias1, void* h_out1, float* c_out1,
+                                        void* stream)
+{
+    if (B < 0 || H <= 0 || H % NSLICE || kh <= 0) return FDYN_ERR_BAD_SIZE;
+    if (!x || !W0 || !bias0 || !h_out0 || !h_prev0 || !c_prev0 || !W1 || !bias1 || !h_out1 || !h_prev1 || !c_prev1) return FDYN_ERR_NULL;
+    if (B == 0) return FDYN_OK;
+    const bool aliased = h_out0 == h_prev0 || (c_out0 && c_out0 == c_prev0) || h_out1 == h_prev1 || (c_out1 && c_out1 == c_prev1);
+    if (aliased && !(fdyn_lstm_cell_mfma_inplace_ok(kx, kh, H, B) && c_out0 && c_out1)) return FDYN_ERR_BAD_SIZE;
+    if (use_mfma64() && B >= 128 * 256) {
+        const int rc = fdyn_lstm_cell_mfma64_pair_try(x, kx, keep, kh, B, H, h_prev0, c_prev0, W0, bias0, h_out0, c_out0,
+                                                      h_prev1, c_prev1, W1, bias1, h_out1, c_out1, stream);
+        if (rc) return rc > 0 ? FDYN_OK : int(hipGetLastError());
+    }
+    const int e = fdyn_lstm_cell_mfma(x, kx, h_prev0, kh, c_prev0, keep, W0, bias0, h_out0, c_out0, nullptr, B, H, stream);
+    return e != FDYN_OK ? e : fdyn_lstm_cell_mfma(x, kx, h_prev1, kh, c_prev1, keep, W1, bias1, h_out1, c_out1, nullptr, B, H, stream);
+}
+
 // BPTT forward of the same cell: besides h' and c' the kernel leaves what the backward pass needs -- the activated gates
 // (bf16 [B][act_gates * H]; zero-state layers, kh = 0, use the three-gate layout (i, g, o) and take c_out = NULL) -- and packs
 // h' * keep_next into the recurrent columns of the next step's input row.  The [B, 4H] pre-activations never exist in HBM:

@@ -97,13 +97,27 @@ __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x)
 __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 constexpr float L2E = 1.4426950408889634f;
 
+// One cell's operands.  A launch takes TWO sets (blockIdx.y picks one): the policy's actor and critic cells read the same x and are
+// independent, so one launch of 2 x B / 256 workgroups runs them back to back on every CU -- no second launch, and a CU that is
+// done with its actor block starts its critic block while slower CUs finish.
+struct CellArgs {
+    const uint16_t* x; const uint16_t* h_prev; const float* c_prev; const float* keep;      // [B][KX] bf16, [B][KH] bf16, [B][H], [B] or null
+    const uint16_t* W; const float* bias; uint16_t* h_out; float* c_out;                  // [4H][KX+KH] bf16, [4H], [B][H] bf16, [B][H]
+};
+
 template <int KX, int KH, int H>
 __global__ void __launch_bounds__(256, 1)
-lstm_cell_mfma64_kernel(const uint16_t* __restrict__ x /*[B][KX] bf16*/, const uint16_t* __restrict__ h_prev /*[B][KH] bf16*/,
-                        const float* __restrict__ c_prev /*[B][H]*/, const float* __restrict__ keep /*[B] or null*/,
-                        const uint16_t* __restrict__ W /*[4H][KX+KH] bf16*/, const float* __restrict__ bias /*[4H]*/,
-                        uint16_t* __restrict__ h_out /*[B][H] bf16*/, float* __restrict__ c_out /*[B][H]*/)
+lstm_cell_mfma64_kernel(CellArgs a0, CellArgs a1)
 {
+    const bool second = blockIdx.y != 0;                  // scalar selects
+    const uint16_t* __restrict__ x = second ? a1.x : a0.x;
+    const uint16_t* __restrict__ h_prev = second ? a1.h_prev : a0.h_prev;
+    const float* __restrict__ c_prev = second ? a1.c_prev : a0.c_prev;
+    const float* __restrict__ keep = second ? a1.keep : a0.keep;
+    const uint16_t* __restrict__ W = second ? a1.W : a0.W;
+    const float* __restrict__ bias = second ? a1.bias : a0.bias;
+    uint16_t* __restrict__ h_out = second ? a1.h_out : a0.h_out;
+    float* __restrict__ c_out = second ? a1.c_out : a0.c_out;
     constexpr int K = KX + KH;
     constexpr int KSTEPS = K / 16;
     constexpr int XSTEPS = KX / 16;
@@ -395,7 +409,21 @@ extern "C" int fdyn_lstm_cell_mfma64_try(const void* x, int kx, const void* h_pr
                                          const void* W, const float* bias, void* h_out, float* c_out, int64_t B, int H, void* stream)
 {
     if (!(kx == 128 && kh == 256 && H == 256) || B <= 0 || B % BM64 || !c_out || !c_prev || !h_prev) return 0;
-    hipLaunchKernelGGL((lstm_cell_mfma64_kernel<128, 256, 256>), dim3(unsigned(B / BM64)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint16_t*)x, (const uint16_t*)h_prev, c_prev, keep, (const uint16_t*)W, bias, (uint16_t*)h_out, c_out);
+    const CellArgs a = { (const uint16_t*)x, (const uint16_t*)h_prev, c_prev, keep, (const uint16_t*)W, bias, (uint16_t*)h_out, c_out };
+    hipLaunchKernelGGL((lstm_cell_mfma64_kernel<128, 256, 256>), dim3(unsigned(B / BM64)), dim3(256), 0, (hipStream_t)stream, a, a);
+    return hipGetLastError() == hipSuccess ? 1 : -1;
+}
+
+// two independent cells on the same x and keep (actor, critic) in ONE launch; same return convention
+extern "C" int fdyn_lstm_cell_mfma64_pair_try(const void* x, int kx, const float* keep, int kh, int64_t B, int H,
+                                              const void* h_prev0, const float* c_prev0, const void* W0, const float* bias0, void* h_out0, float* c_out0,
+                                              const void* h_prev1, const float* c_prev1, const void* W1, const float* bias1, void* h_out1, float* c_out1,
+                                              void* stream)
+{
+    if (!(kx == 128 && kh == 256 && H == 256) || B <= 0 || B % BM64) return 0;
+    if (!c_out0 || !c_prev0 || !h_prev0 || !c_out1 || !c_prev1 || !h_prev1) return 0;
+    const CellArgs a0 = { (const uint16_t*)x, (const uint16_t*)h_prev0, c_prev0, keep, (const uint16_t*)W0, bias0, (uint16_t*)h_out0, c_out0 };
+    const CellArgs a1 = { (const uint16_t*)x, (const uint16_t*)h_prev1, c_prev1, keep, (const uint16_t*)W1, bias1, (uint16_t*)h_out1, c_out1 };
+    hipLaunchKernelGGL((lstm_cell_mfma64_kernel<128, 256, 256>), dim3(unsigned(B / BM64), 2), dim3(256), 0, (hipStream_t)stream, a0, a1);
     return hipGetLastError() == hipSuccess ? 1 : -1;
 }

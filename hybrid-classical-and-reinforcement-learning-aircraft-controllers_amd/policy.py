@@ -365,6 +365,7 @@ class RateLSTMPolicy(nn.Module):
             feats = self._mlp_bf16(x, inf["proj"])
         out = []
         outs = (None, None, None, None) if out_states is None else tuple(out_states)
+        cells = []
         for (w, b, hp, cp), (ho, co) in zip(((inf["pi_w"], inf["pi_b"], states.pi_h, states.pi_c),
                                              (inf["vf_w"], inf["vf_b"], states.vf_h, states.vf_c)), (outs[0:2], outs[2:4])):
             hp, cp = hp.to(bf).contiguous(), cp.float().contiguous()
@@ -376,10 +377,16 @@ class RateLSTMPolicy(nn.Module):
                 and ((ho.data_ptr() != hp.data_ptr() and co.data_ptr() != cp.data_ptr()) or lib.fdyn_lstm_cell_mfma_inplace_ok(128, H, H, B))
             h = ho if ok else torch.empty((B, H), dtype=bf, device=dev)
             c = co if ok else torch.empty((B, H), dtype=torch.float32, device=dev)
-            _lib.check(lib.fdyn_lstm_cell_mfma(feats.data_ptr(), feats.shape[1], hp.data_ptr(), H, cp.data_ptr(),
-                                               keep.data_ptr(), w.data_ptr(), b.data_ptr(), h.data_ptr(), c.data_ptr(), None,
-                                               B, H, st), "lstm_cell_mfma")
+            cells.append((hp, cp, w, b, h, c))
             out += [h, c]
+        # actor and critic cell in one launch (fdyn_lstm_cell_mfma_pair falls back to two where the paired kernel does not apply)
+        if os.environ.get("FDYN_NO_CELL_PAIR"):             # A/B knob: the two launches of rounds 1-2
+            for hp, cp, w, b, h, c in cells:
+                _lib.check(lib.fdyn_lstm_cell_mfma(feats.data_ptr(), feats.shape[1], hp.data_ptr(), H, cp.data_ptr(), keep.data_ptr(),
+                                                   w.data_ptr(), b.data_ptr(), h.data_ptr(), c.data_ptr(), None, B, H, st), "lstm_cell_mfma")
+        else:
+            _lib.check(lib.fdyn_lstm_cell_mfma_pair(feats.data_ptr(), feats.shape[1], keep.data_ptr(), H, B, H,
+                                                    *[t.data_ptr() for cell in cells for t in cell], st), "lstm_cell_mfma_pair")
         # the two trunks; the 64 -> 4 and 64 -> 1 output layers are fused with the sampling (fdyn_policy_heads)
         if "trunk_w1" in inf and H == 256 and not os.environ.get("FDYN_NO_TRUNK"):
             h_pi, h_vf = out[0], out[2]

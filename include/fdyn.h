@@ -256,6 +256,14 @@ int fdyn_lstm_cell_mfma(const void* x, int kx, const void* h_prev, int kh, const
  * is what lets the two cells' state (201 MB) live in the 256 MB Infinity Cache from one rollout step to the next (measured:
  * rollout step 0.279 -> 0.261 ms).  Any other shape given aliased state is refused with FDYN_ERR_BAD_SIZE.                  */
 int fdyn_lstm_cell_mfma_inplace_ok(int kx, int kh, int H, int64_t B);
+/* Two cells of the same shape on the same x and keep -- MlpLstmPolicy's actor and critic LSTM
+ * (learned_controllers/networks/lstm_policy.py:107-136, sb3_contrib's separate lstm_actor / lstm_critic) -- in ONE launch where
+ * the one-wave-per-SIMD kernel applies (kx = 128, kh = H = 256, B a multiple of 256 and >= 32 768), otherwise as two calls of
+ * fdyn_lstm_cell_mfma.  Operand meaning and the in-place rule as there; both cells need c_out.                               */
+int fdyn_lstm_cell_mfma_pair(const void* x, int kx, const float* keep, int kh, int64_t B, int H,
+                             const void* h_prev0, const float* c_prev0, const void* W0, const float* bias0, void* h_out0, float* c_out0,
+                             const void* h_prev1, const float* c_prev1, const void* W1, const float* bias1, void* h_out1, float* c_out1,
+                             void* stream);
 /* BOTH recurrent cells of the rollout policy (sb3_contrib MlpLstmPolicy's actor and critic nn.LSTM(128, 256) over the shared
  * features; reference net sizes learned_controllers/networks/lstm_policy.py:107-136) as ONE launch with lane = batch row
  * (csrc/policy_rc64.hip).  Operands live in the kernel's own layouts (policy.py: rc_pack_x / rc_pack_h / rc_pack_c convert from

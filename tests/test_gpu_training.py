@@ -836,6 +836,40 @@ def test_recurrent_state_in_place_equals_ping_pong():
     assert rc == _lib.FDYN_ERR_BAD_SIZE
 
 
+@pytest.mark.parametrize("B,inplace", [(65536, False), (65536, True), (32768, True), (512, False)])
+def test_cell_pair_in_one_launch_equals_two_launches(B, inplace):
+    """fdyn_lstm_cell_mfma_pair (actor and critic cell, one launch of 2 x B / 256 workgroups where the one-wave-per-SIMD kernel
+    applies; two calls elsewhere) against two calls of fdyn_lstm_cell_mfma: the same kernel on the same operands, bit for bit --
+    out of place and with the state updated in place; aliased state at a shape the paired kernel does not serve is refused."""
+    from hcrl_amd import _lib
+    torch.manual_seed(B + int(inplace))
+    lib, bf, st = _lib.load(), torch.bfloat16, _lib.current_stream()
+    x = (torch.randn(B, 128, device="cuda") * 0.7).to(bf)
+    keep = (torch.rand(B, device="cuda") > 0.05).float()
+    W = [(torch.randn(1024, 384, device="cuda") * 0.06).to(bf) for _ in range(2)]
+    bias = [torch.randn(1024, device="cuda") * 0.3 for _ in range(2)]
+    h0 = [(torch.randn(B, 256, device="cuda") * 0.5).to(bf) for _ in range(2)]
+    c0 = [torch.randn(B, 256, device="cuda") for _ in range(2)]
+    ref = []
+    for g in range(2):
+        h, c = torch.empty_like(h0[g]), torch.empty_like(c0[g])
+        _lib.check(lib.fdyn_lstm_cell_mfma(x.data_ptr(), 128, h0[g].data_ptr(), 256, c0[g].data_ptr(), keep.data_ptr(), W[g].data_ptr(),
+                                           bias[g].data_ptr(), h.data_ptr(), c.data_ptr(), None, B, 256, st), "lstm_cell_mfma")
+        ref += [h, c]
+    hin, cin = [t.clone() for t in h0], [t.clone() for t in c0]
+    hout = hin if inplace else [torch.empty_like(t) for t in h0]
+    cout = cin if inplace else [torch.empty_like(t) for t in c0]
+    args = [t.data_ptr() for g in range(2) for t in (hin[g], cin[g], W[g], bias[g], hout[g], cout[g])]
+    _lib.check(lib.fdyn_lstm_cell_mfma_pair(x.data_ptr(), 128, keep.data_ptr(), 256, B, 256, *args, st), "lstm_cell_mfma_pair")
+    torch.cuda.synchronize()
+    for g in range(2):
+        assert torch.equal(hout[g], ref[2 * g]) and torch.equal(cout[g], ref[2 * g + 1]), g
+    assert not torch.equal(ref[0], ref[2])                                       # the two cells really differ
+    if B == 512:
+        args = [t.data_ptr() for g in range(2) for t in (hin[g], cin[g], W[g], bias[g], hin[g], cin[g])]
+        assert lib.fdyn_lstm_cell_mfma_pair(x.data_ptr(), 128, keep.data_ptr(), 256, B, 256, *args, st) == _lib.FDYN_ERR_BAD_SIZE
+
+
 @pytest.mark.parametrize("B", [300, 65536])
 def test_heads_behind_the_trunks_equal_the_two_launch_path(B, monkeypatch):
     """fdyn_policy_trunks_heads (trunks -> output heads -> Gaussian sampling in one launch, lat never leaves the registers)
