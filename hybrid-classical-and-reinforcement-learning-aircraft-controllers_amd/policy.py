@@ -78,6 +78,9 @@ def _run_seq(seq, x):
 _KPERM16 = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)
 
 
+FE_GATE_SCALE = (-1.4426950408889634, 1.0, -2.0 * 1.4426950408889634, -1.4426950408889634)     # gates i, f (unused), g, o
+
+
 def pack_fe_weights(w_emb, w1, w2, w_proj):
     """The features extractor's four weight matrices as the byte image csrc/policy_fe64.hip streams through LDS.
 
@@ -99,8 +102,12 @@ def pack_fe_weights(w_emb, w1, w2, w_proj):
         return torch.cat([img, torch.zeros(pad, dtype=bf, device=rows.device)])
 
     parts = [chunk(F.pad(w_emb.detach().float(), (0, 32 - w_emb.shape[1])))]
+    # rows of the LSTM layers pre-scaled (in fp32, before the one rounding to bf16) by the factor their gate's exponent takes:
+    # sigmoid(z) = 1 / (1 + 2^(-z log2 e)) for i and o, tanh(z) = (1 - 2^(-2 z log2 e)) / (1 + ...) for g -- the kernel's
+    # accumulators (which start from the equally scaled biases) then ARE the exponents: FE_GATE_SCALE
+    gate_scale = torch.tensor(FE_GATE_SCALE, dtype=torch.float32, device=w1.device).repeat_interleave(H)[:, None]
     for w in (w1, w2):
-        wp = w.detach().float()[:, perm(w.shape[1])]
+        wp = (w.detach().float() * gate_scale)[:, perm(w.shape[1])]
         for s in range(H // 32):
             parts.append(chunk(torch.cat([wp[32 * s:32 * s + 32], wp[2 * H + 32 * s:2 * H + 32 * s + 32]], 0)))
             parts.append(chunk(wp[3 * H + 32 * s:3 * H + 32 * s + 32]))

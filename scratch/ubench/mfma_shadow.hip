@@ -11,6 +11,11 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 constexpr int ITERS = 1024;
 
+#define MFMA_A() asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c0) : "v"(a), "v"(b))
+#define MFMA_B() asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c1) : "v"(a), "v"(b))
+#define FMA2()  asm volatile("v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3" : "+v"(x0), "+v"(x1) : "v"(m), "v"(d))
+#define EXP2()  asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1" : "+v"(x4), "+v"(x5))
+#define LDSR()  asm volatile("ds_read_b128 %0, %1" : "=v"(lw) : "v"(laddr))
 #define MFMA2() asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n v_mfma_f32_32x32x16_bf16 %1, %2, %3, %1" : "+v"(c0), "+v"(c1) : "v"(a), "v"(b))
 #define FMA4()  asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(m), "v"(d))
 #define FMA4B() asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5" : "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(m), "v"(d))
@@ -35,6 +40,9 @@ template <int MODE, int THREADS> __global__ void __launch_bounds__(THREADS, 1) k
     v2 p0 = {x0, x1}, p1 = {x2, x3}, p2 = {x4, x5}, p3 = {x6, x7};
     const v2 pm = {m, m}, pd = {d, d};
     const int wave = threadIdx.x >> 6;
+    __shared__ u32x4_t lds[256];
+    lds[threadIdx.x & 255] = a;
+    u32x4_t lw = a; const uint32_t laddr = (threadIdx.x & 63) * 16;
     constexpr int PH = 12;                                  // iterations per phase: 24 MFMAs = one 32-row tile over K = 384
     __syncthreads();
     const uint64_t t0 = __builtin_amdgcn_s_memtime();
@@ -51,6 +59,22 @@ template <int MODE, int THREADS> __global__ void __launch_bounds__(THREADS, 1) k
             if constexpr (MODE == 7) { MFMA2(); PK4(); }
             if constexpr (MODE == 8) { MFMA2(); EXP4(); }
             if constexpr (MODE == 9) { MFMA2(); EXP4(); FMA4B(); }
+        }
+    } else if constexpr (MODE >= 20 && MODE < 40) {
+#pragma unroll 4
+        for (int i = 0; i < ITERS; ++i) {
+            if constexpr (MODE == 20) { MFMA_A(); FMA2(); MFMA_B(); FMA2(); }
+            if constexpr (MODE == 21) { MFMA_A(); FMA4(); MFMA_B(); FMA4B(); }
+            if constexpr (MODE == 22) { MFMA_A(); FMA4(); FMA2(); MFMA_B(); FMA4B(); FMA2(); }
+            if constexpr (MODE == 23) { MFMA_A(); FMA4(); FMA4B(); MFMA_B(); FMA4(); FMA4B(); }
+            if constexpr (MODE == 24) { MFMA_A(); EXP2(); MFMA_B(); EXP2(); }
+            if constexpr (MODE == 25) { MFMA_A(); EXP4(); MFMA_B(); EXP4B(); }
+            if constexpr (MODE == 26) { MFMA_A(); EXP2(); FMA2(); MFMA_B(); EXP2(); FMA2(); }
+            if constexpr (MODE == 27) { MFMA_A(); EXP4(); FMA4B(); MFMA_B(); EXP4(); FMA4B(); }
+            if constexpr (MODE == 28) { MFMA_A(); LDSR(); FMA4(); MFMA_B(); FMA4B(); }
+            if constexpr (MODE == 29) { MFMA_A(); LDSR(); MFMA_B(); }
+            if constexpr (MODE == 30) { MFMA_A(); FMA4(); FMA4B(); FMA4(); MFMA_B(); FMA4B(); FMA4(); FMA4B(); }
+            if constexpr (MODE == 31) { MFMA_A(); FMA4(); __builtin_amdgcn_sched_barrier(0); MFMA_B(); FMA4B(); __builtin_amdgcn_sched_barrier(0); }
         }
     } else if constexpr (MODE == 10 || MODE == 11) {
         if (wave < 4) {
@@ -84,7 +108,7 @@ template <int MODE, int THREADS> __global__ void __launch_bounds__(THREADS, 1) k
         }
     }
     const uint64_t t1 = __builtin_amdgcn_s_memtime();
-    float acc = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + p0[0] + p0[1] + p1[0] + p1[1] + p2[0] + p2[1] + p3[0] + p3[1];
+    float acc = __builtin_bit_cast(float, lw.x) + x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + p0[0] + p0[1] + p1[0] + p1[1] + p2[0] + p2[1] + p3[0] + p3[1];
     for (int e = 0; e < 16; ++e) acc += c0[e] + c1[e];
     out[blockIdx.x * THREADS + threadIdx.x] = acc;
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
@@ -126,6 +150,18 @@ int main()
     run<8, 256>(out, cyc, src, " 8: 1 wave/SIMD  2 MFMA + 4 exp", 2.0 * ITERS, "");
     run<2, 256>(out, cyc, src, " 2: 1 wave/SIMD  2 MFMA + 8 exp", 2.0 * ITERS, "");
     run<9, 256>(out, cyc, src, " 9: 1 wave/SIMD  2 MFMA + 4 exp + 4 fma", 2.0 * ITERS, "");
+    run<20, 256>(out, cyc, src, "20: MFMA, 2 fma, MFMA, 2 fma", 2.0 * ITERS, "");
+    run<21, 256>(out, cyc, src, "21: MFMA, 4 fma, MFMA, 4 fma", 2.0 * ITERS, "");
+    run<22, 256>(out, cyc, src, "22: MFMA, 6 fma, MFMA, 6 fma", 2.0 * ITERS, "");
+    run<23, 256>(out, cyc, src, "23: MFMA, 8 fma, MFMA, 8 fma", 2.0 * ITERS, "");
+    run<30, 256>(out, cyc, src, "30: MFMA, 12 fma, MFMA, 12 fma", 2.0 * ITERS, "");
+    run<24, 256>(out, cyc, src, "24: MFMA, 2 exp, MFMA, 2 exp", 2.0 * ITERS, "");
+    run<25, 256>(out, cyc, src, "25: MFMA, 4 exp, MFMA, 4 exp", 2.0 * ITERS, "");
+    run<26, 256>(out, cyc, src, "26: MFMA, 2 exp + 2 fma, MFMA, 2 exp + 2 fma", 2.0 * ITERS, "");
+    run<27, 256>(out, cyc, src, "27: MFMA, 4 exp + 4 fma, MFMA, 4 exp + 4 fma", 2.0 * ITERS, "");
+    run<28, 256>(out, cyc, src, "28: MFMA, ds_read_b128 + 4 fma, MFMA, 4 fma", 2.0 * ITERS, "");
+    run<29, 256>(out, cyc, src, "29: MFMA, ds_read_b128, MFMA", 2.0 * ITERS, "");
+    run<31, 256>(out, cyc, src, "31: as 21 with sched_barrier(0) after each group", 2.0 * ITERS, "");
     run<10, 512>(out, cyc, src, "10: 2 waves/SIMD one 2 MFMA, the other 16 fma", 2.0 * ITERS, "");
     run<11, 512>(out, cyc, src, "11: 2 waves/SIMD one 2 MFMA, the other 8 exp + 8 fma", 2.0 * ITERS, "");
     run<12, 512>(out, cyc, src, "12: 2 waves/SIMD both 2 MFMA + 8 fma", 4.0 * ITERS, "");

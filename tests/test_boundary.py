@@ -210,9 +210,10 @@ seed: 42
 
 def test_fe_weight_image_layout():
     """policy.pack_fe_weights lays the features extractor's weights out as csrc/policy_fe64.hip streams them: chunk order, row
-    padding, 1 KB chunk granularity and the k order inside blocks of 16 (replayed here from the kernel's constants)."""
+    padding, 1 KB chunk granularity, the k order inside blocks of 16 (replayed here from the kernel's constants) and the LSTM
+    rows scaled by their gate's exponent factor before the rounding to bf16."""
     import torch
-    from hcrl_amd.policy import pack_fe_weights, _KPERM16
+    from hcrl_amd.policy import pack_fe_weights, _KPERM16, FE_GATE_SCALE
     torch.manual_seed(0)
     bf = torch.bfloat16
     w_emb, w1, w2, wp = (torch.randn(128, 18).to(bf).float(), torch.randn(1024, 128).to(bf).float(),
@@ -225,6 +226,8 @@ def test_fe_weight_image_layout():
     off_c = off_b + 8 * (pieces(64, 256) + pieces(32, 256))
     assert img.numel() * 2 == (off_c + 4 * pieces(32, 256)) * 1024 == 702464
 
+    sc = lambda w, gate: (w * FE_GATE_SCALE[gate]).to(bf).float().item()      # noqa: E731
+
     def at(piece_off, K, row, k):                     # element (row, k-slot) of the chunk that starts at `piece_off`
         return img[piece_off * 512 + row * (K + 8) + k].item()
     assert at(0, 32, 5, 7) == w_emb[5, 7].item() and at(0, 32, 5, 20) == 0.0
@@ -232,9 +235,9 @@ def test_fe_weight_image_layout():
     o1 = off_a + s * (pieces(64, 128) + pieces(32, 128))
     for slot in (0, 5, 9, 127):
         k = 16 * (slot // 16) + _KPERM16[slot % 16]
-        assert at(o1, 128, 2, slot) == w1[32 * s + 2, k].item()                     # gate i
-        assert at(o1, 128, 32 + 2, slot) == w1[512 + 32 * s + 2, k].item()          # gate g
-        assert at(o1 + pieces(64, 128), 128, 2, slot) == w1[768 + 32 * s + 2, k].item()   # gate o
+        assert at(o1, 128, 2, slot) == sc(w1[32 * s + 2, k], 0)                     # gate i
+        assert at(o1, 128, 32 + 2, slot) == sc(w1[512 + 32 * s + 2, k], 2)          # gate g
+        assert at(o1 + pieces(64, 128), 128, 2, slot) == sc(w1[768 + 32 * s + 2, k], 3)   # gate o
     o2 = off_b + 7 * (pieces(64, 256) + pieces(32, 256))
-    assert at(o2, 256, 40, 200) == w2[512 + 224 + 8, 16 * 12 + _KPERM16[8]].item()
+    assert at(o2, 256, 40, 200) == sc(w2[512 + 224 + 8, 16 * 12 + _KPERM16[8]], 2)
     assert at(off_c + 2 * pieces(32, 256), 256, 31, 37) == wp[64 + 31, 32 + _KPERM16[5]].item()

@@ -723,6 +723,7 @@ def test_policy_features_kernel_matches_plain_torch_fp32(B):
     and against the layer-wise device path it replaces.  Random weights with non-zero biases and an asymmetric observation
     batch: a wrong k permutation, fragment order or gate offset cannot pass."""
     from hcrl_amd import _lib
+    from hcrl_amd.policy import FE_GATE_SCALE
     lib = _lib.load()
     torch.manual_seed(11)
     p = RateLSTMPolicy(compute_dtype=torch.bfloat16).cuda()
@@ -740,7 +741,9 @@ def test_policy_features_kernel_matches_plain_torch_fp32(B):
     bf = lambda t: t.to(torch.bfloat16).float()      # noqa: E731
     x = bf(torch.relu(bf(obs) @ bf(fe.embedding[0].weight).t() + fe.embedding[0].bias))
     for k in range(2):
-        w = bf(getattr(fe.lstm, f"weight_ih_l{k}")); b = getattr(fe.lstm, f"bias_ih_l{k}") + getattr(fe.lstm, f"bias_hh_l{k}")
+        # the weight image holds the LSTM rows scaled by their gate's exponent factor and THEN rounded to bf16 (FE_GATE_SCALE)
+        gs = torch.tensor(FE_GATE_SCALE, device="cuda").repeat_interleave(256)[:, None]
+        w = bf(getattr(fe.lstm, f"weight_ih_l{k}") * gs) / gs; b = getattr(fe.lstm, f"bias_ih_l{k}") + getattr(fe.lstm, f"bias_hh_l{k}")
         i, _, g, o = (x @ w.t() + b).chunk(4, 1)
         x = bf(torch.sigmoid(o) * torch.tanh(torch.sigmoid(i) * torch.tanh(g)))
     ref = torch.relu(x @ bf(fe.output_proj[0].weight).t() + fe.output_proj[0].bias)
