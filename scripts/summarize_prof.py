@@ -49,7 +49,7 @@ meta = {}
 for path in newest_per_dir(glob.glob(os.path.join(prof, "p*", "**", "*_counter_collection.csv"), recursive=True)):
     for r in csv.DictReader(open(path)):
         k = short(r["Kernel_Name"])
-        if not any(s in k for s in ("rate_env", "sixdof", "cascade", "lstm", "gate", "policy_fe")):
+        if not any(s in k for s in ("rate_env", "sixdof", "cascade", "lstm", "gate", "policy_fe", "policy_trunk")):
             continue
         pmc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         meta[k] = {"grid": int(r["Grid_Size"]), "workgroup": int(r["Workgroup_Size"]), "lds": int(r["LDS_Block_Size"]),
