@@ -133,20 +133,17 @@ policy_fe64_kernel(const float* __restrict__ obs /*[B][18]*/, const uint8_t* __r
     req_all(0, NP_EMB, 0);
     req_all(OFF_A, NP_A_IG, 1);
 
-    if (fl.term) {                                      // episode_start / keep of this step's rows, the action-noise counter
-        const int64_t row = int64_t(blockIdx.x) * 256 + tid;
-        const bool done = (fl.term[row] | fl.trunc[row]) != 0;
-        if (fl.episode_start) fl.episode_start[row] = done ? 1.0f : 0.0f;
-        if (fl.keep) fl.keep[row] = done ? 0.0f : 1.0f;
-        if (fl.counter && blockIdx.x == 0 && tid == 0) fl.counter[0] += 1;
-    }
-
-    // ---- biases -> LDS, pre-scaled like their weight rows (policy.py: pack_fe_weights): i, o: -log2 e; g: -2 log2 e; Linear layers: 1
-    for (int i = tid; i < EMB + 8 * H + FEAT; i += 256) {
-        float sc = 1.0f;
-        if (i >= SB_1 && i < SB_P) { const int gate = ((i - SB_1) % (4 * H)) / H; sc = gate == 2 ? -2.0f * L2E : -L2E; }
-        s_b[i] = bias[i] * sc;
-    }
+    // ---- every load of the prologue is issued before the first of them is waited for (round 3: as a rolled load -> scale -> LDS
+    // loop the nine bias words of a thread were nine dependent L2 round trips -- most of the 12 k cycles in front of the embedding,
+    // profiles/r03_fe64_ns7.log -- and the flag bytes a tenth): flags, biases, observations; then their consumers.
+    const int64_t frow = int64_t(blockIdx.x) * 256 + tid;
+    uint8_t fterm = 0, ftrunc = 0;
+    if (fl.term) { fterm = fl.term[frow]; ftrunc = fl.trunc[frow]; }
+    constexpr int NBV = (EMB + 8 * H + FEAT) / 256;
+    static_assert((EMB + 8 * H + FEAT) % 256 == 0, "whole bias words per thread");
+    float bvals[NBV];
+#pragma unroll
+    for (int j = 0; j < NBV; ++j) bvals[j] = bias[tid + 256 * j];
     // ---- observation fragments: lane (b, hf) holds k = 16 ks + 8 hf .. + 7 of its row for ks = 0, 1 (k >= 18 is zero)
     bf16x8_t xo[2][2];
     {
@@ -166,6 +163,20 @@ policy_fe64_kernel(const float* __restrict__ obs /*[B][18]*/, const uint8_t* __r
                 xo[t][ks] = __builtin_bit_cast(bf16x8_t, u);
             }
         }
+    }
+    if (fl.term) {                                      // episode_start / keep of this step's rows, the action-noise counter
+        const bool done = (fterm | ftrunc) != 0;
+        if (fl.episode_start) fl.episode_start[frow] = done ? 1.0f : 0.0f;
+        if (fl.keep) fl.keep[frow] = done ? 0.0f : 1.0f;
+        if (fl.counter && blockIdx.x == 0 && tid == 0) fl.counter[0] += 1;
+    }
+    // ---- biases -> LDS, pre-scaled like their weight rows (policy.py: pack_fe_weights): i, o: -log2 e; g: -2 log2 e; Linear layers: 1
+#pragma unroll
+    for (int j = 0; j < NBV; ++j) {
+        const int i = tid + 256 * j;
+        float sc = 1.0f;
+        if (i >= SB_1 && i < SB_P) { const int gate = ((i - SB_1) % (4 * H)) / H; sc = gate == 2 ? -2.0f * L2E : -L2E; }
+        s_b[i] = bvals[j] * sc;
     }
     wait_vm0();
     __syncthreads();
