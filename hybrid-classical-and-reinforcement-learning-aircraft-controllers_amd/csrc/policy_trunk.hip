@@ -199,9 +199,12 @@ policy_trunk_kernel(const uint16_t* __restrict__ h_pi, const uint16_t* __restric
             constexpr int t0 = 2 * decltype(NP)::value;
             f32x16_t acc1[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)                  // the accumulators start from the biases (one add per element less in the epilogue)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc1[t][e] = 0.0f;
+                for (int j = 0; j < 4; ++j) {
+                    const float4 bb = *reinterpret_cast<const float4*>(s_b1 + 32 * (t0 + t) + 8 * j + 4 * hf);
+                    acc1[t][4 * j] = bb.x; acc1[t][4 * j + 1] = bb.y; acc1[t][4 * j + 2] = bb.z; acc1[t][4 * j + 3] = bb.w;
+                }
             u32x4_t an[2][2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) an[0][t] = *reinterpret_cast<const u32x4_t*>(wr1 + 32 * (t0 + t) * ROW1);
@@ -223,11 +226,9 @@ policy_trunk_kernel(const uint16_t* __restrict__ h_pi, const uint16_t* __restric
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
                         const int j = 2 * q + jj;                                      // e >> 2
-                        const float4 bb = *reinterpret_cast<const float4*>(s_b1 + 32 * (t0 + t) + 8 * j + 4 * hf);
-                        const float bv[4] = { bb.x, bb.y, bb.z, bb.w };
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            const float v = acc1[t][4 * j + i] + bv[i];
+                            const float v = acc1[t][4 * j + i];
                             f[4 * jj + i] = static_cast<__bf16>(v > 0.0f ? v : 0.0f);
                         }
                     }
@@ -241,7 +242,10 @@ policy_trunk_kernel(const uint16_t* __restrict__ h_pi, const uint16_t* __restric
 #pragma unroll
         for (int t = 0; t < N2 / 32; ++t)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc2[t][e] = 0.0f;
+            for (int j = 0; j < 4; ++j) {
+                const float4 bb = *reinterpret_cast<const float4*>(s_b2 + 32 * t + 8 * j + 4 * hf);
+                acc2[t][4 * j] = bb.x; acc2[t][4 * j + 1] = bb.y; acc2[t][4 * j + 2] = bb.z; acc2[t][4 * j + 3] = bb.w;
+            }
         const uint16_t* wr2 = s_w2 + r * ROW2 + 8 * hf;
         asm volatile("" : "+v"(wr2));
         u32x4_t cn[2][N2 / 32];
@@ -266,12 +270,10 @@ policy_trunk_kernel(const uint16_t* __restrict__ h_pi, const uint16_t* __restric
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
                     const int j = 2 * q + jj;
-                    const float4 bb = *reinterpret_cast<const float4*>(s_b2 + 32 * t + 8 * j + 4 * hf);
-                    const float bv[4] = { bb.x, bb.y, bb.z, bb.w };
                     bf16x4_t o;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const float v = acc2[t][4 * j + i] + bv[i];
+                        const float v = acc2[t][4 * j + i];
                         o[i] = static_cast<__bf16>(v > 0.0f ? v : 0.0f);
                         f[4 * jj + i] = o[i];
                     }
