@@ -873,6 +873,41 @@ def test_cell_pair_in_one_launch_equals_two_launches(B, inplace):
         assert lib.fdyn_lstm_cell_mfma_pair(x.data_ptr(), 128, keep.data_ptr(), 256, B, 256, *args, st) == _lib.FDYN_ERR_BAD_SIZE
 
 
+def test_policy_entry_points_validate_their_arguments():
+    """The policy-step entry points added in round 3 return the library's error codes instead of launching on bad arguments:
+    NULL operands, negative / unsupported sizes; an empty batch is a no-op."""
+    from hcrl_amd import _lib
+    lib, bf, st = _lib.load(), torch.bfloat16, _lib.current_stream()
+    B = 512
+    x = torch.zeros(B, 128, device="cuda", dtype=bf)
+    h = [torch.zeros(B, 256, device="cuda", dtype=bf) for _ in range(4)]
+    c = [torch.zeros(B, 256, device="cuda") for _ in range(4)]
+    W = torch.zeros(1024, 384, device="cuda", dtype=bf); b = torch.zeros(1024, device="cuda")
+    good = [h[0].data_ptr(), c[0].data_ptr(), W.data_ptr(), b.data_ptr(), h[1].data_ptr(), c[1].data_ptr(),
+            h[2].data_ptr(), c[2].data_ptr(), W.data_ptr(), b.data_ptr(), h[3].data_ptr(), c[3].data_ptr()]
+    pair = lib.fdyn_lstm_cell_mfma_pair
+    assert pair(x.data_ptr(), 128, None, 256, B, 256, *good, st) == 0                       # keep may be NULL (nobody restarted)
+    assert pair(x.data_ptr(), 128, None, 256, 0, 256, *good, st) == 0                       # empty batch
+    assert pair(None, 128, None, 256, B, 256, *good, st) == _lib.FDYN_ERR_NULL
+    assert pair(x.data_ptr(), 128, None, 256, B, 256, *good[:8], None, *good[9:], st) == _lib.FDYN_ERR_NULL
+    assert pair(x.data_ptr(), 128, None, 256, -1, 256, *good, st) == _lib.FDYN_ERR_BAD_SIZE
+    assert pair(x.data_ptr(), 128, None, 0, B, 256, *good, st) == _lib.FDYN_ERR_BAD_SIZE    # a pair of zero-state cells is not a thing
+    assert pair(x.data_ptr(), 64, None, 256, B, 256, *good, st) == _lib.FDYN_ERR_BAD_SIZE   # unsupported input width
+    w1 = torch.zeros(2, 128, 256, device="cuda", dtype=bf); b1 = torch.zeros(2, 128, device="cuda")
+    w2 = torch.zeros(2, 64, 128, device="cuda", dtype=bf); b2 = torch.zeros(2, 64, device="cuda")
+    wa = torch.zeros(4, 64, device="cuda", dtype=bf); ba = torch.zeros(4, device="cuda", dtype=bf)
+    wv = torch.zeros(64, device="cuda", dtype=bf); bv = torch.zeros(1, device="cuda", dtype=bf)
+    ls = torch.zeros(4, device="cuda"); act = torch.full((B, 4), 3.0, device="cuda"); lp = torch.empty(B, device="cuda"); val = torch.empty(B, device="cuda")
+    th = lib.fdyn_policy_trunks_heads
+    args = [h[0].data_ptr(), h[2].data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), wa.data_ptr(), ba.data_ptr(),
+            wv.data_ptr(), bv.data_ptr(), ls.data_ptr(), 7, None, 1, act.data_ptr(), lp.data_ptr(), val.data_ptr()]
+    assert th(*args, 0, st) == 0 and th(*args, -5, st) == _lib.FDYN_ERR_BAD_SIZE
+    assert th(*args[:6], None, *args[7:], B, st) == _lib.FDYN_ERR_NULL
+    assert th(*args, B, st) == 0                                                              # step counter NULL = counter 0
+    torch.cuda.synchronize()
+    assert float(act.abs().max()) == 0.0 and float(val.abs().max()) == 0.0                  # zero weights, deterministic: zeros out
+
+
 @pytest.mark.parametrize("B", [300, 65536])
 def test_heads_behind_the_trunks_equal_the_two_launch_path(B, monkeypatch):
     """fdyn_policy_trunks_heads (trunks -> output heads -> Gaussian sampling in one launch, lat never leaves the registers)
